@@ -1,0 +1,121 @@
+/*
+ * rrt_hip.h -- C ABI of the MI355X (gfx950) RRT / RRT* tree-expansion engine.
+ *
+ * The reference (rland93/rrtplanner) has no FFI: its boundary is the body of
+ * RRTStandard.plan / RRTStar.plan / RRTStarInformed.plan (rrtplanner/rrt.py:386-447,
+ * :466-556, :653-758).  This header is the boundary a maintainer binds instead of those
+ * loops (INTEGRATION.md shows the ctypes stub).  Plain C: pointers and sizes only, no
+ * torch / numpy types.  All functions return 0 (RRT_OK) or a positive "host action
+ * needed" status or a negative error; no exception crosses the boundary.
+ * rrt_last_error_string() describes the last failure.
+ *
+ * Threading: a ctx (and the batches made from it) is used by one host thread at a
+ * time; distinct ctxs are independent (each owns a HIP stream).
+ */
+#ifndef RRT_HIP_H
+#define RRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRT_OK 0
+#define RRT_NEED_UNITBALL 1        /* Informed: query reached ellipse sampling (rrt.py:697) without unit-ball data */
+#define RRT_E_ARG (-1)
+#define RRT_E_GOAL_UNREACHABLE (-2) /* rrt.py:317-318 would index og[INT64_MIN,..]: no line of sight, j < n */
+#define RRT_E_HIP (-3)
+#define RRT_E_NOGRID (-4)
+#define RRT_E_UNSUPPORTED (-5)     /* grid larger than 2048 x 2048 (packed-key fast path), n > 262144 */
+#define RRT_E_COMM (-6)
+
+#define RRT_ALG_STANDARD 0 /* RRTStandard.plan     rrt.py:386 */
+#define RRT_ALG_STAR 1     /* RRTStar.plan         rrt.py:466 */
+#define RRT_ALG_INFORMED 2 /* RRTStarInformed.plan rrt.py:653 */
+
+#define RRT_FLAG_LOGS 1u /* keep per-iteration logs (nearest, accept, ellipse cost, j) on the device */
+
+typedef struct rrt_ctx rrt_ctx;
+typedef struct rrt_batch rrt_batch;
+
+/* One planning query == the arguments of plan() plus the planner's state that the loop
+ * reads (rrt.py:51-85, :454-464, :563-577). */
+typedef struct rrt_query {
+    int32_t alg;            /* RRT_ALG_* */
+    int32_t n;              /* self.n: attempted samples and node capacity (rrt.py:62) */
+    int32_t xs[2];          /* xstart */
+    int32_t xg[2];          /* xgoal */
+    int64_t r2_rewire;      /* smallest integer R with (d2 < r_rewire*r_rewire) <=> (d2 < R)   (rrt.py:180) */
+    int64_t goal_d2;        /* smallest integer G with (r2norm(d) < r_goal) <=> (d2 < G)      (rrt.py:744) */
+    const int32_t *samples; /* host (n,2): free[rand_gen.choice(F)] for iteration i (rrt.py:240) */
+    double C[4];            /* Informed: rotation_to_world_frame(xstart,xgoal), row-major (rrt.py:601-613) */
+} rrt_query;
+
+/* Result of one query: the arrays plan() hands to build_graph (rrt.py:334-369).
+ * pts/vcost/parent are caller-allocated with n+1 rows; rows [0, rows) are written.
+ * Optional logs (NULL to skip, need RRT_FLAG_LOGS) have n rows. */
+typedef struct rrt_result {
+    int32_t *pts;         /* (n+1,2) */
+    double *vcost;        /* (n+1)   */
+    int32_t *parent;      /* (n+1)   -1 = root / none */
+    int32_t *nearest_log; /* (n) vnearest of iteration i */
+    uint8_t *accept_log;  /* (n) 1 if iteration i inserted a node */
+    double *cbest_log;    /* (n) ellipse cost c of iteration i (rrt.py:698-699), NaN when free-sampled */
+    int32_t *j_log;       /* (n) j at the top of iteration i (key of self.ellipses, rrt.py:701) */
+    int32_t status;       /* RRT_OK / RRT_NEED_UNITBALL / RRT_E_GOAL_UNREACHABLE */
+    int32_t j;            /* tree nodes before go2goal */
+    int32_t vgoal;        /* rrt.py:319 / :331 */
+    int32_t found;        /* go2goal connected the goal */
+    int32_t i_switch;     /* first iteration sampled from the ellipse (n if none) */
+    int32_t rows;         /* len(points) after go2goal: j+1 live rows are valid; n+1 if found else n in the reference */
+    int64_t sum_j;        /* statistics for the algorithmic-byte model */
+    int64_t sum_cells_nn;
+    int64_t sum_near;
+    int64_t sum_cells_cand;
+    int64_t n_los_cand;
+} rrt_result;
+
+/* ---- context / grid -------------------------------------------------------------- */
+int rrt_ctx_create(int32_t device_id, rrt_ctx **out);
+int rrt_ctx_destroy(rrt_ctx *ctx);
+const char *rrt_last_error_string(rrt_ctx *ctx); /* ctx may be NULL */
+/* RRT.__init__ / set_og (rrt.py:64-65, :261-272): og_nonzero is (W,H) C-order, 1 = obstacle. */
+int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, int32_t H);
+
+/* ---- resident batches: Q independent queries on the ctx's grid ------------------------- */
+int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t flags, rrt_batch **out);
+int rrt_batch_destroy(rrt_batch *b);
+int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *query); /* uploads samples, arms query q */
+/* Informed: unit-ball points (rrt.py:582-586) for iterations ub_offset .. ub_offset+count-1 */
+int rrt_batch_set_unitball(rrt_batch *b, int32_t q, const double *unitball, int32_t count, int32_t ub_offset);
+int rrt_batch_rearm(rrt_batch *b);  /* reset every query's tree, keep the uploaded inputs */
+int rrt_batch_launch(rrt_batch *b); /* asynchronous on the ctx stream; runs / resumes every unfinished query */
+int rrt_batch_sync(rrt_batch *b);
+int rrt_batch_elapsed_ms(rrt_batch *b, float *ms); /* HIP events around the last launch's kernels */
+int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out);
+/* device-resident packed result block of the batch (for the multi-GPU gather) */
+int rrt_batch_result_block(rrt_batch *b, void **dev_ptr, int64_t *bytes);
+
+/* ---- one-shot wrappers (what plan() binds) --------------------------------------------- */
+int rrt_plan(rrt_ctx *ctx, const rrt_query *query, uint32_t flags, rrt_result *out);
+int rrt_plan_resume(rrt_ctx *ctx, const double *unitball, int32_t count, rrt_result *out);
+int rrt_plan_batch(rrt_ctx *ctx, int32_t Q, const rrt_query *queries, rrt_result *out);
+
+/* ---- primitives of the path (parity tests, micro-benchmarks) --------------------------- */
+/* RRT.collisionfree (rrt.py:183-229) for m segments ab[k] = {ax,ay,bx,by}; cells = grid cells the
+ * reference's walk reads before it returns. */
+int rrt_prim_collisionfree(rrt_ctx *ctx, const int32_t *ab, int32_t m, uint8_t *out_free, int32_t *out_cells);
+/* near()[0] (rrt.py:150-155,:422) and |within()| (rrt.py:176-181) of m query points against j nodes */
+int rrt_prim_nearest_within(rrt_ctx *ctx, const int32_t *pts, int32_t j, const int32_t *xq, int32_t m,
+                            int64_t r2, int32_t *out_nearest, int32_t *out_within_count,
+                            int64_t *out_within_idxsum);
+/* sqrt of the integers lo .. lo+count-1 as the kernels compute it (r2norm, rrt.py:24) */
+int rrt_prim_sqrt_u32(rrt_ctx *ctx, uint32_t lo, uint32_t count, double *out);
+/* sqrt of arbitrary doubles as the kernels compute it (ellipse minor axis, rrt.py:622) */
+int rrt_prim_sqrt_f64(rrt_ctx *ctx, const double *in, uint32_t count, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_HIP_H */

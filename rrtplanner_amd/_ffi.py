@@ -1,0 +1,291 @@
+"""ctypes binding of the C ABI in include/rrt_hip.h (librrt_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded, or no GPU
+is visible, the functions here raise.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C rrtplanner_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librrt_hip.so")
+
+RRT_OK = 0
+RRT_NEED_UNITBALL = 1
+RRT_E_ARG = -1
+RRT_E_GOAL_UNREACHABLE = -2
+RRT_E_HIP = -3
+RRT_E_NOGRID = -4
+RRT_E_UNSUPPORTED = -5
+RRT_E_COMM = -6
+
+ALG_STANDARD, ALG_STAR, ALG_INFORMED = 0, 1, 2
+FLAG_LOGS = 1
+
+# every symbol include/rrt_hip.h declares (tests/test_capi_symbols.py checks the library exports them)
+SYMBOLS = (
+    "rrt_ctx_create", "rrt_ctx_destroy", "rrt_last_error_string", "rrt_set_grid",
+    "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
+    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_elapsed_ms",
+    "rrt_batch_get_result", "rrt_batch_result_block",
+    "rrt_plan", "rrt_plan_resume", "rrt_plan_batch",
+    "rrt_prim_collisionfree", "rrt_prim_nearest_within", "rrt_prim_sqrt_u32", "rrt_prim_sqrt_f64",
+)
+
+
+class RRTError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librrt_hip error {code}: {msg}")
+        self.code = code
+
+
+class Query(C.Structure):
+    _fields_ = [
+        ("alg", C.c_int32), ("n", C.c_int32),
+        ("xs", C.c_int32 * 2), ("xg", C.c_int32 * 2),
+        ("r2_rewire", C.c_int64), ("goal_d2", C.c_int64),
+        ("samples", C.c_void_p),
+        ("C", C.c_double * 4),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("pts", C.c_void_p), ("vcost", C.c_void_p), ("parent", C.c_void_p),
+        ("nearest_log", C.c_void_p), ("accept_log", C.c_void_p), ("cbest_log", C.c_void_p), ("j_log", C.c_void_p),
+        ("status", C.c_int32), ("j", C.c_int32), ("vgoal", C.c_int32), ("found", C.c_int32),
+        ("i_switch", C.c_int32), ("rows", C.c_int32),
+        ("sum_j", C.c_int64), ("sum_cells_nn", C.c_int64), ("sum_near", C.c_int64), ("sum_cells_cand", C.c_int64),
+        ("n_los_cand", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Load librrt_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  rrtplanner_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        vp, i32, u32, i64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64
+        sig = {
+            "rrt_ctx_create": ([i32, C.POINTER(vp)], C.c_int),
+            "rrt_ctx_destroy": ([vp], C.c_int),
+            "rrt_last_error_string": ([vp], C.c_char_p),
+            "rrt_set_grid": ([vp, vp, i32, i32], C.c_int),
+            "rrt_batch_create": ([vp, i32, i32, u32, C.POINTER(vp)], C.c_int),
+            "rrt_batch_destroy": ([vp], C.c_int),
+            "rrt_batch_set_query": ([vp, i32, C.POINTER(Query)], C.c_int),
+            "rrt_batch_set_unitball": ([vp, i32, vp, i32, i32], C.c_int),
+            "rrt_batch_rearm": ([vp], C.c_int),
+            "rrt_batch_launch": ([vp], C.c_int),
+            "rrt_batch_sync": ([vp], C.c_int),
+            "rrt_batch_elapsed_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
+            "rrt_batch_get_result": ([vp, i32, C.POINTER(Result)], C.c_int),
+            "rrt_batch_result_block": ([vp, C.POINTER(vp), C.POINTER(i64)], C.c_int),
+            "rrt_plan": ([vp, C.POINTER(Query), u32, C.POINTER(Result)], C.c_int),
+            "rrt_plan_resume": ([vp, vp, i32, C.POINTER(Result)], C.c_int),
+            "rrt_plan_batch": ([vp, i32, C.POINTER(Query), C.POINTER(Result)], C.c_int),
+            "rrt_prim_collisionfree": ([vp, vp, i32, vp, vp], C.c_int),
+            "rrt_prim_nearest_within": ([vp, vp, i32, vp, i32, i64, vp, vp, vp], C.c_int),
+            "rrt_prim_sqrt_u32": ([vp, u32, u32, vp], C.c_int),
+            "rrt_prim_sqrt_f64": ([vp, vp, u32, vp], C.c_int),
+        }
+        for name, (argtypes, restype) in sig.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def _check(ctx_handle, rc, ok=(RRT_OK,)):
+    if rc in ok:
+        return rc
+    msg = lib().rrt_last_error_string(ctx_handle)
+    raise RRTError(rc, msg.decode() if msg else "")
+
+
+class ResultArrays:
+    """Host buffers for one query's result + the filled-in rrt_result."""
+
+    def __init__(self, n, logs=False):
+        self.n = n
+        self.pts = np.zeros((n + 1, 2), dtype=np.int32)
+        self.vcost = np.zeros(n + 1, dtype=np.float64)
+        self.parent = np.full(n + 1, -1, dtype=np.int32)
+        self.c = Result()
+        self.c.pts, self.c.vcost, self.c.parent = self.pts.ctypes.data, self.vcost.ctypes.data, self.parent.ctypes.data
+        if logs:
+            self.nearest_log = np.full(n, -1, dtype=np.int32)
+            self.accept_log = np.zeros(n, dtype=np.uint8)
+            self.cbest_log = np.full(n, np.nan)
+            self.j_log = np.zeros(n, dtype=np.int32)
+            self.c.nearest_log, self.c.accept_log = self.nearest_log.ctypes.data, self.accept_log.ctypes.data
+            self.c.cbest_log, self.c.j_log = self.cbest_log.ctypes.data, self.j_log.ctypes.data
+
+    def __getattr__(self, k):  # scalars live in the C struct
+        if k in ("status", "j", "vgoal", "found", "i_switch", "rows", "sum_j", "sum_cells_nn", "sum_near",
+                 "sum_cells_cand", "n_los_cand"):
+            return getattr(self.c, k)
+        raise AttributeError(k)
+
+
+def make_query(alg, n, xs, xg, samples, r2_rewire=0, goal_d2=0, Cmat=None):
+    """Build an rrt_query; returns (Query, keepalive)."""
+    s = np.ascontiguousarray(samples, dtype=np.int32)
+    if s.shape != (n, 2):
+        raise ValueError(f"samples must have shape ({n}, 2), got {s.shape}")
+    q = Query()
+    q.alg, q.n = int(alg), int(n)
+    q.xs[0], q.xs[1] = int(xs[0]), int(xs[1])
+    q.xg[0], q.xg[1] = int(xg[0]), int(xg[1])
+    q.r2_rewire, q.goal_d2 = int(r2_rewire), int(goal_d2)
+    q.samples = s.ctypes.data
+    if Cmat is not None:
+        cm = np.asarray(Cmat, dtype=np.float64).reshape(4)
+        for k in range(4):
+            q.C[k] = float(cm[k])
+    return q, s
+
+
+class Context:
+    """One device context: a HIP stream + the device-resident occupancy grid."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        rc = lib().rrt_ctx_create(int(device_id), C.byref(self._h))
+        _check(None, rc)
+        self.shape = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().rrt_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_grid(self, og_nonzero):
+        g = np.ascontiguousarray(og_nonzero, dtype=np.uint8)
+        if g.ndim != 2:
+            raise ValueError("occupancy grid must be 2-D")
+        _check(self._h, lib().rrt_set_grid(self._h, g.ctypes.data, g.shape[0], g.shape[1]))
+        self.shape = g.shape
+
+    # ---- one-shot ----
+    def plan(self, query, n, logs=False):
+        res = ResultArrays(n, logs)
+        rc = lib().rrt_plan(self._h, C.byref(query), FLAG_LOGS if logs else 0, C.byref(res.c))
+        _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
+        return rc, res
+
+    def plan_resume(self, unitball, res):
+        ub = np.ascontiguousarray(unitball, dtype=np.float64)
+        rc = lib().rrt_plan_resume(self._h, ub.ctypes.data, ub.shape[0], C.byref(res.c))
+        _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
+        return rc
+
+    # ---- primitives ----
+    def prim_collisionfree(self, ab):
+        ab = np.ascontiguousarray(ab, dtype=np.int32).reshape(-1, 4)
+        m = ab.shape[0]
+        free = np.zeros(m, dtype=np.uint8)
+        cells = np.zeros(m, dtype=np.int32)
+        _check(self._h, lib().rrt_prim_collisionfree(self._h, ab.ctypes.data, m, free.ctypes.data, cells.ctypes.data))
+        return free.astype(bool), cells
+
+    def prim_nearest_within(self, pts, xq, r2):
+        pts = np.ascontiguousarray(pts, dtype=np.int32).reshape(-1, 2)
+        xq = np.ascontiguousarray(xq, dtype=np.int32).reshape(-1, 2)
+        m = xq.shape[0]
+        nn = np.zeros(m, dtype=np.int32)
+        cnt = np.zeros(m, dtype=np.int32)
+        isum = np.zeros(m, dtype=np.int64)
+        _check(self._h, lib().rrt_prim_nearest_within(self._h, pts.ctypes.data, pts.shape[0], xq.ctypes.data, m, int(r2),
+                                                      nn.ctypes.data, cnt.ctypes.data, isum.ctypes.data))
+        return nn, cnt, isum
+
+    def prim_sqrt_u32(self, lo, count):
+        out = np.zeros(count, dtype=np.float64)
+        _check(self._h, lib().rrt_prim_sqrt_u32(self._h, int(lo), int(count), out.ctypes.data))
+        return out
+
+    def prim_sqrt_f64(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros_like(x)
+        _check(self._h, lib().rrt_prim_sqrt_f64(self._h, x.ctypes.data, x.size, out.ctypes.data))
+        return out
+
+
+class Batch:
+    """Q independent queries resident on the device (rrt_batch_*)."""
+
+    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False):
+        self.ctx, self.Q, self.n_cap, self.logs = ctx, int(Q), int(n_cap), logs
+        self._h = C.c_void_p()
+        _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, FLAG_LOGS if logs else 0, C.byref(self._h)))
+        self._n = [0] * self.Q
+
+    def close(self):
+        if self._h:
+            lib().rrt_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_query(self, q, query):
+        _check(self.ctx.handle, lib().rrt_batch_set_query(self._h, int(q), C.byref(query)))
+        self._n[q] = query.n
+
+    def set_unitball(self, q, unitball, ub_offset):
+        ub = np.ascontiguousarray(unitball, dtype=np.float64)
+        _check(self.ctx.handle, lib().rrt_batch_set_unitball(self._h, int(q), ub.ctypes.data, ub.shape[0], int(ub_offset)))
+
+    def rearm(self):
+        _check(self.ctx.handle, lib().rrt_batch_rearm(self._h))
+
+    def launch(self):
+        _check(self.ctx.handle, lib().rrt_batch_launch(self._h))
+
+    def sync(self):
+        _check(self.ctx.handle, lib().rrt_batch_sync(self._h))
+
+    def elapsed_ms(self):
+        ms = C.c_float(0)
+        _check(self.ctx.handle, lib().rrt_batch_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def get_result(self, q, arrays=True):
+        res = ResultArrays(self._n[q], self.logs) if arrays else None
+        if res is None:
+            res = ResultArrays.__new__(ResultArrays)
+            res.n = self._n[q]
+            res.c = Result()
+        rc = lib().rrt_batch_get_result(self._h, int(q), C.byref(res.c))
+        _check(self.ctx.handle, rc, ok=(RRT_OK, RRT_E_GOAL_UNREACHABLE))
+        return res
+
+    def result_block(self):
+        p, nbytes = C.c_void_p(), C.c_int64()
+        _check(self.ctx.handle, lib().rrt_batch_result_block(self._h, C.byref(p), C.byref(nbytes)))
+        return p.value, nbytes.value

@@ -1,0 +1,94 @@
+// rrt_device.h -- device-side building blocks shared by the kernels of rrt_engine.hip.
+// gfx950 only (wave64, DPP row_bcast, v_pk_sub_i16 / v_dot2c_i32_i16).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rrt_line.h"
+
+namespace rrtdev {
+
+constexpr int TPB = 1024;          // threads of one query workgroup (16 waves, one CU)
+constexpr int NWAVE = TPB / 64;
+constexpr int CHUNK = TPB * 4;     // nodes per scan chunk: one 16-byte load per thread
+constexpr int MAX_LDS_CHUNKS = 8;  // node chunks cached in LDS (8 * 16 KiB = 128 KiB)
+constexpr int CANDCAP = 1536;      // near-set entries per LDS list (2 lists * 12 KiB)
+constexpr uint32_t NONE = 0xffffffffu;
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+// Nodes and samples are packed int16x2: x in the low half, y in the high half.  Grids are
+// at most 2048 x 2048 on this path, so x,y < 2^11 and d2 < 2^23.
+__device__ __forceinline__ uint32_t pack_xy(int x, int y) { return ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16); }
+__device__ __forceinline__ int ux(uint32_t p) { return (int)(p & 0xffffu); }
+__device__ __forceinline__ int uy(uint32_t p) { return (int)(p >> 16); }
+
+// Squared distance of two packed points: v_pk_sub_i16 + v_dot2c_i32_i16.
+__device__ __forceinline__ uint32_t dist2(uint32_t a, uint32_t b) {
+    short2_t d = __builtin_bit_cast(short2_t, a) - __builtin_bit_cast(short2_t, b);
+    return (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
+}
+
+// Wave-wide unsigned minimum, result uniform in every lane.  DPP row_shr 1/2/4/8 leaves each
+// row's minimum in its lane 15; row_bcast:15 / row_bcast:31 fold the four rows into lane 63.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Lexicographic wave minimum of (key, idx): smallest key, lowest idx among equal keys.
+__device__ __forceinline__ void wave_min_key_idx(uint32_t &key, uint32_t &idx) {
+    uint32_t mk = wave_min_u32(key);
+    uint32_t mi = wave_min_u32(key == mk ? idx : NONE);
+    key = mk;
+    idx = mi;
+}
+
+// Lexicographic wave minimum of (c, idx) for non-negative doubles (their bit patterns order
+// like unsigned integers); +inf / NONE means "nothing".
+__device__ __forceinline__ void wave_min_f64_idx(double &c, uint32_t &idx) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(c);
+    uint32_t hi = (uint32_t)(b >> 32), lo = (uint32_t)b;
+    uint32_t mh = wave_min_u32(hi);
+    uint32_t ml = wave_min_u32(hi == mh ? lo : NONE);
+    uint32_t mi = wave_min_u32((hi == mh && lo == ml) ? idx : NONE);
+    c = __longlong_as_double((long long)(((unsigned long long)mh << 32) | ml));
+    idx = mi;
+}
+
+// r2norm of an integer difference (rrt.py:24): sqrt of an exact integer < 2^53.
+__device__ __forceinline__ double sqrt_u32(uint32_t d2) { return sqrt((double)d2); }
+
+// Line of sight a -> b (RRT.collisionfree, rrt.py:202-229) evaluated by one wavefront:
+// lane l tests cell k0+l of the closed-form walk (rrt_line.h); the ballot gives any-hit and
+// the first blocked cell.  `cells` = grid cells the reference's serial walk reads
+// before returning (first blocked cell + 1, or L+1).  Result uniform.
+__device__ __forceinline__ bool los_wave(const uint8_t *__restrict__ og, int H, uint32_t a, uint32_t b, int lane,
+                                         int &cells) {
+    rrt_line_t l = rrt_line_setup(ux(a), uy(a), ux(b), uy(b));
+    const int L = l.major;
+    for (int k0 = 0; k0 <= L; k0 += 64) {
+        int k = k0 + lane;
+        bool occ = false;
+        if (k <= L) {
+            int x, y;
+            rrt_line_cell(&l, k, &x, &y);
+            occ = og[(size_t)x * H + y] != 0;
+        }
+        unsigned long long m = __ballot(occ);
+        if (m) {
+            cells = k0 + (int)__builtin_ctzll(m) + 1;
+            return false;
+        }
+    }
+    cells = L + 1;
+    return true;
+}
+
+}  // namespace rrtdev

@@ -1,0 +1,556 @@
+// rrt_engine.hip -- C ABI (include/rrt_hip.h) over the gfx950 kernels of rrt_kernels.h.
+// Host side: HIP memory, one stream per context, events for kernel timing.  No torch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rrt_hip.h"
+#include "rrt_kernels.h"
+#include "rrt_prims.h"
+
+using namespace rrtdev;
+
+static thread_local std::string g_last_error;
+
+struct rrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *og = nullptr;  // device (W,H)
+    int32_t W = 0, H = 0;
+    std::string err;
+    rrt_batch *single = nullptr;  // batch behind rrt_plan / rrt_plan_resume
+    uint32_t single_flags = 0;
+    int max_lds = 0;
+};
+
+struct rrt_batch {
+    rrt_ctx *ctx = nullptr;
+    int32_t Q = 0, n_cap = 0, node_stride = 0, bitmap_words = 0, lds_chunks = 1;
+    int32_t gridW = 0, gridH = 0;
+    uint32_t flags = 0;
+    QDesc *d_desc = nullptr;
+    std::vector<QDesc> h_desc;
+    uint32_t *d_samples = nullptr, *d_nodes = nullptr, *d_bitmap = nullptr;
+    double *d_vcost = nullptr, *d_unitball = nullptr, *d_cbest_log = nullptr;
+    int32_t *d_parent = nullptr, *d_nearest_log = nullptr, *d_j_log = nullptr;
+    uint8_t *d_accept_log = nullptr;
+    uint2 *d_spill = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::vector<uint32_t> stage;  // host staging for packed samples
+};
+
+static int fail(rrt_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, RRT_E_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
+    } while (0)
+
+extern "C" const char *rrt_last_error_string(rrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int rrt_ctx_create(int32_t device_id, rrt_ctx **out) {
+    if (!out) return fail(nullptr, RRT_E_ARG, "rrt_ctx_create: out is NULL");
+    int ndev = 0;
+    HIPCHK(nullptr, hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev)
+        return fail(nullptr, RRT_E_ARG, "rrt_ctx_create: device %d of %d", device_id, ndev);
+    HIPCHK(nullptr, hipSetDevice(device_id));
+    rrt_ctx *c = new rrt_ctx();
+    c->device = device_id;
+    HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(nullptr, hipDeviceGetAttribute(&c->max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id));
+    *out = c;
+    return RRT_OK;
+}
+
+extern "C" int rrt_ctx_destroy(rrt_ctx *ctx) {
+    if (!ctx) return RRT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->single) rrt_batch_destroy(ctx->single);
+    if (ctx->og) (void)hipFree(ctx->og);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RRT_OK;
+}
+
+extern "C" int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, int32_t H) {
+    if (!ctx || !og_nonzero || W < 1 || H < 1) return fail(ctx, RRT_E_ARG, "rrt_set_grid: bad argument");
+    if (W > 2048 || H > 2048)
+        return fail(ctx, RRT_E_UNSUPPORTED, "rrt_set_grid: %dx%d exceeds the 2048x2048 packed-key path", W, H);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->og && (size_t)ctx->W * ctx->H != (size_t)W * H) {
+        HIPCHK(ctx, hipFree(ctx->og));
+        ctx->og = nullptr;
+    }
+    if (!ctx->og) HIPCHK(ctx, hipMalloc(&ctx->og, (size_t)W * H));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->og, og_nonzero, (size_t)W * H, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->W = W;
+    ctx->H = H;
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_destroy(rrt_batch *b) {
+    if (!b) return RRT_OK;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    void *ptrs[] = {b->d_desc,   b->d_samples,  b->d_nodes,     b->d_bitmap,      b->d_vcost, b->d_unitball,
+                    b->d_parent, b->d_spill,    b->d_cbest_log, b->d_nearest_log, b->d_j_log, b->d_accept_log};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->ctx->single == b) b->ctx->single = nullptr;
+    delete b;
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t flags, rrt_batch **out) {
+    if (!ctx || !out || Q < 1 || n_cap < 1) return fail(ctx, RRT_E_ARG, "rrt_batch_create: bad argument");
+    if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_batch_create: call rrt_set_grid first");
+    if ((long long)n_cap + 1 > 64LL * CHUNK)
+        return fail(ctx, RRT_E_UNSUPPORTED, "rrt_batch_create: n=%d exceeds %d nodes", n_cap, 64 * CHUNK - 1);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rrt_batch *b = new rrt_batch();
+    b->ctx = ctx;
+    b->Q = Q;
+    b->n_cap = n_cap;
+    b->flags = flags;
+    b->gridW = ctx->W;
+    b->gridH = ctx->H;
+    b->node_stride = ((n_cap + 4) + 3) & ~3;
+    b->bitmap_words = (int32_t)(((size_t)ctx->W * ctx->H + 31) / 32);
+    int chunks = (n_cap + 1 + CHUNK - 1) / CHUNK;
+    b->lds_chunks = chunks < 1 ? 1 : (chunks > MAX_LDS_CHUNKS ? MAX_LDS_CHUNKS : chunks);
+    b->h_desc.assign((size_t)Q, QDesc{});
+    for (auto &d : b->h_desc) d.status = ST_IDLE;
+    const size_t q = (size_t)Q;
+#define ALLOC(ptr, bytes)                                   \
+    do {                                                    \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes)); \
+        if (e_ != hipSuccess) {                             \
+            rrt_batch_destroy(b);                           \
+            return fail(ctx, RRT_E_HIP, "hipMalloc(%zu): %s", (size_t)(bytes), hipGetErrorString(e_)); \
+        }                                                   \
+    } while (0)
+    ALLOC(b->d_desc, q * sizeof(QDesc));
+    ALLOC(b->d_samples, q * n_cap * sizeof(uint32_t));
+    ALLOC(b->d_nodes, q * b->node_stride * sizeof(uint32_t));
+    ALLOC(b->d_vcost, q * b->node_stride * sizeof(double));
+    ALLOC(b->d_parent, q * b->node_stride * sizeof(int32_t));
+    ALLOC(b->d_bitmap, q * b->bitmap_words * sizeof(uint32_t));
+    ALLOC(b->d_spill, q * n_cap * sizeof(uint2));
+    if (flags & RRT_FLAG_LOGS) {
+        ALLOC(b->d_nearest_log, q * n_cap * sizeof(int32_t));
+        ALLOC(b->d_accept_log, q * n_cap * sizeof(uint8_t));
+        ALLOC(b->d_cbest_log, q * n_cap * sizeof(double));
+        ALLOC(b->d_j_log, q * n_cap * sizeof(int32_t));
+    }
+#undef ALLOC
+    HIPCHK(ctx, hipMemsetAsync(b->d_nodes, 0, q * b->node_stride * sizeof(uint32_t), ctx->stream));
+    HIPCHK(ctx, hipEventCreate(&b->ev0));
+    HIPCHK(ctx, hipEventCreate(&b->ev1));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_desc, b->h_desc.data(), q * sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = b;
+    return RRT_OK;
+}
+
+static void arm_desc(QDesc &d) {
+    d.status = ST_RUNNING;
+    d.i = 0;
+    d.j = 1;
+    d.nsoln = 0;
+    d.vbest_soln = -1;
+    d.cmin_soln = INFINITY;
+    d.vgoal = 0;
+    d.found = 0;
+    d.i_switch = d.n;
+    d.ub_offset = 0;
+    d.ub_count = 0;
+    d.sum_j = d.sum_cells_nn = d.sum_near = d.sum_cells_cand = d.n_los_cand = 0;
+}
+
+extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu) {
+    if (!b || !qu) return fail(nullptr, RRT_E_ARG, "rrt_batch_set_query: NULL");
+    rrt_ctx *ctx = b->ctx;
+    if (q < 0 || q >= b->Q) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: q=%d of %d", q, b->Q);
+    if (qu->alg < 0 || qu->alg > 2) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: alg=%d", qu->alg);
+    if (qu->n < 1 || qu->n > b->n_cap) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: n=%d, capacity %d", qu->n, b->n_cap);
+    if (b->gridW != ctx->W || b->gridH != ctx->H)
+        return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: grid changed shape since rrt_batch_create");
+    const int W = ctx->W, H = ctx->H;
+    if (qu->xs[0] < 0 || qu->xs[0] >= W || qu->xs[1] < 0 || qu->xs[1] >= H || qu->xg[0] < 0 || qu->xg[0] >= W ||
+        qu->xg[1] < 0 || qu->xg[1] >= H)
+        return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: start/goal outside the %dx%d grid", W, H);
+    if (!qu->samples) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: samples is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    b->stage.resize((size_t)qu->n);
+    for (int k = 0; k < qu->n; ++k) {
+        const int x = qu->samples[2 * k], y = qu->samples[2 * k + 1];
+        if (x < 0 || x >= W || y < 0 || y >= H) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: sample %d outside the grid", k);
+        b->stage[(size_t)k] = ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16);
+    }
+    QDesc &d = b->h_desc[(size_t)q];
+    d = QDesc{};
+    d.alg = qu->alg;
+    d.n = qu->n;
+    d.xs[0] = qu->xs[0];
+    d.xs[1] = qu->xs[1];
+    d.xg[0] = qu->xg[0];
+    d.xg[1] = qu->xg[1];
+    const int64_t cap = 1 << 24;  // any d2 on a 2048x2048 grid is below this
+    d.r2_rewire = (uint32_t)(qu->r2_rewire < 0 ? 0 : (qu->r2_rewire > cap ? cap : qu->r2_rewire));
+    d.goal_d2 = (uint32_t)(qu->goal_d2 < 0 ? 0 : (qu->goal_d2 > cap ? cap : qu->goal_d2));
+    for (int k = 0; k < 4; ++k) d.C[k] = qu->C[k];
+    arm_desc(d);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_samples + (size_t)q * b->n_cap, b->stage.data(), (size_t)qu->n * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b->d_desc + q, &d, sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // staging buffer is reused
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_set_unitball(rrt_batch *b, int32_t q, const double *unitball, int32_t count, int32_t ub_offset) {
+    if (!b || !unitball) return fail(nullptr, RRT_E_ARG, "rrt_batch_set_unitball: NULL");
+    rrt_ctx *ctx = b->ctx;
+    if (q < 0 || q >= b->Q || count < 0 || ub_offset < 0 || (long long)ub_offset + count > b->n_cap)
+        return fail(ctx, RRT_E_ARG, "rrt_batch_set_unitball: bad range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!b->d_unitball) HIPCHK(ctx, hipMalloc((void **)&b->d_unitball, (size_t)b->Q * 2 * b->n_cap * sizeof(double)));
+    QDesc &d = b->h_desc[(size_t)q];
+    if (d.status != ST_NEED_UB) return fail(ctx, RRT_E_ARG, "rrt_batch_set_unitball: query %d is not waiting for unit-ball data", q);
+    // entries are indexed by iteration - ub_offset on the device
+    HIPCHK(ctx, hipMemcpyAsync(b->d_unitball + (size_t)q * 2 * b->n_cap, unitball, (size_t)count * 2 * sizeof(double),
+                               hipMemcpyHostToDevice, ctx->stream));
+    d.ub_offset = ub_offset;
+    d.ub_count = count;
+    d.status = ST_RUNNING;
+    HIPCHK(ctx, hipMemcpyAsync(b->d_desc + q, &d, sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_rearm(rrt_batch *b) {
+    if (!b) return fail(nullptr, RRT_E_ARG, "rrt_batch_rearm: NULL");
+    rrt_ctx *ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (auto &d : b->h_desc)
+        if (d.status != ST_IDLE) arm_desc(d);
+    HIPCHK(ctx, hipMemcpyAsync(b->d_desc, b->h_desc.data(), (size_t)b->Q * sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream));
+    return RRT_OK;
+}
+
+static BatchView make_view(rrt_batch *b) {
+    BatchView v{};
+    v.desc = b->d_desc;
+    v.samples = b->d_samples;
+    v.nodes = b->d_nodes;
+    v.vcost = b->d_vcost;
+    v.parent = b->d_parent;
+    v.bitmap = b->d_bitmap;
+    v.spill = b->d_spill;
+    v.unitball = b->d_unitball;
+    v.nearest_log = b->d_nearest_log;
+    v.accept_log = b->d_accept_log;
+    v.cbest_log = b->d_cbest_log;
+    v.j_log = b->d_j_log;
+    v.og = b->ctx->og;
+    v.W = b->ctx->W;
+    v.H = b->ctx->H;
+    v.n_cap = b->n_cap;
+    v.node_stride = b->node_stride;
+    v.bitmap_words = b->bitmap_words;
+    v.lds_chunks = b->lds_chunks;
+    return v;
+}
+
+static size_t expand_lds_bytes(int lds_chunks) {
+    return (size_t)lds_chunks * CHUNK * sizeof(uint32_t) + 2 * (size_t)CANDCAP * sizeof(uint2) + 2 * NWAVE * sizeof(CSlot) +
+           2 * NWAVE * sizeof(uint2) + 16;
+}
+
+extern "C" int rrt_batch_launch(rrt_batch *b) {
+    if (!b) return fail(nullptr, RRT_E_ARG, "rrt_batch_launch: NULL");
+    rrt_ctx *ctx = b->ctx;
+    if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_batch_launch: no grid");
+    if (b->gridW != ctx->W || b->gridH != ctx->H) return fail(ctx, RRT_E_ARG, "rrt_batch_launch: grid changed shape");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    BatchView v = make_view(b);
+    const size_t lds = expand_lds_bytes(b->lds_chunks);
+    if ((int)lds > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds, ctx->max_lds);
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rrt_expand_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
+    hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+    HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
+    hipLaunchKernelGGL(rrt_expand_kernel, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
+    HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    b->timed = true;
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_sync(rrt_batch *b) {
+    if (!b) return fail(nullptr, RRT_E_ARG, "rrt_batch_sync: NULL");
+    rrt_ctx *ctx = b->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(b->h_desc.data(), b->d_desc, (size_t)b->Q * sizeof(QDesc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_elapsed_ms(rrt_batch *b, float *ms) {
+    if (!b || !ms) return fail(nullptr, RRT_E_ARG, "rrt_batch_elapsed_ms: NULL");
+    if (!b->timed) return fail(b->ctx, RRT_E_ARG, "rrt_batch_elapsed_ms: nothing launched");
+    HIPCHK(b->ctx, hipEventElapsedTime(ms, b->ev0, b->ev1));
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out) {
+    if (!b || !out) return fail(nullptr, RRT_E_ARG, "rrt_batch_get_result: NULL");
+    rrt_ctx *ctx = b->ctx;
+    if (q < 0 || q >= b->Q) return fail(ctx, RRT_E_ARG, "rrt_batch_get_result: q=%d of %d", q, b->Q);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const QDesc &d = b->h_desc[(size_t)q];
+    if (d.status == ST_RUNNING || d.status == ST_IDLE)
+        return fail(ctx, RRT_E_ARG, "rrt_batch_get_result: query %d has not run (launch + sync first)", q);
+    out->status = d.status;
+    out->j = d.j;
+    out->vgoal = d.vgoal;
+    out->found = d.found;
+    out->i_switch = d.i_switch;
+    out->rows = d.found ? d.n + 1 : d.n;
+    out->sum_j = (int64_t)d.sum_j;
+    out->sum_cells_nn = (int64_t)d.sum_cells_nn;
+    out->sum_near = (int64_t)d.sum_near;
+    out->sum_cells_cand = (int64_t)d.sum_cells_cand;
+    out->n_los_cand = (int64_t)d.n_los_cand;
+    const int live = d.j + (d.found ? 1 : 0);
+    if (out->pts) {
+        std::vector<uint32_t> tmp((size_t)live);
+        HIPCHK(ctx, hipMemcpyAsync(tmp.data(), b->d_nodes + (size_t)q * b->node_stride, (size_t)live * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < live; ++k) {
+            out->pts[2 * k] = (int32_t)(tmp[(size_t)k] & 0xffffu);
+            out->pts[2 * k + 1] = (int32_t)(tmp[(size_t)k] >> 16);
+        }
+    }
+    if (out->vcost)
+        HIPCHK(ctx, hipMemcpyAsync(out->vcost, b->d_vcost + (size_t)q * b->node_stride, (size_t)live * sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    if (out->parent)
+        HIPCHK(ctx, hipMemcpyAsync(out->parent, b->d_parent + (size_t)q * b->node_stride, (size_t)live * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    const int ni = d.i;  // iterations executed so far
+    if (b->flags & RRT_FLAG_LOGS) {
+        const size_t o = (size_t)q * b->n_cap;
+        if (out->nearest_log)
+            HIPCHK(ctx, hipMemcpyAsync(out->nearest_log, b->d_nearest_log + o, (size_t)ni * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (out->accept_log)
+            HIPCHK(ctx, hipMemcpyAsync(out->accept_log, b->d_accept_log + o, (size_t)ni * sizeof(uint8_t), hipMemcpyDeviceToHost, ctx->stream));
+        if (out->cbest_log)
+            HIPCHK(ctx, hipMemcpyAsync(out->cbest_log, b->d_cbest_log + o, (size_t)ni * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (out->j_log)
+            HIPCHK(ctx, hipMemcpyAsync(out->j_log, b->d_j_log + o, (size_t)ni * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return d.status < 0 ? d.status : RRT_OK;
+}
+
+extern "C" int rrt_batch_result_block(rrt_batch *b, void **dev_ptr, int64_t *bytes) {
+    if (!b || !dev_ptr || !bytes) return fail(nullptr, RRT_E_ARG, "rrt_batch_result_block: NULL");
+    *dev_ptr = b->d_nodes;
+    *bytes = (int64_t)b->Q * b->node_stride * (int64_t)sizeof(uint32_t);
+    return RRT_OK;
+}
+
+// ---- one-shot wrappers -------------------------------------------------------------------
+
+static int ensure_single(rrt_ctx *ctx, int32_t n, uint32_t flags) {
+    rrt_batch *s = ctx->single;
+    if (s && (s->n_cap < n || s->flags != flags || s->gridW != ctx->W || s->gridH != ctx->H)) {
+        rrt_batch_destroy(s);
+        s = nullptr;
+    }
+    if (!s) {
+        int rc = rrt_batch_create(ctx, 1, n, flags, &s);
+        if (rc != RRT_OK) return rc;
+        ctx->single = s;
+    }
+    return RRT_OK;
+}
+
+static int run_single(rrt_ctx *ctx, rrt_result *out) {
+    rrt_batch *s = ctx->single;
+    int rc = rrt_batch_launch(s);
+    if (rc != RRT_OK) return rc;
+    rc = rrt_batch_sync(s);
+    if (rc != RRT_OK) return rc;
+    rc = rrt_batch_get_result(s, 0, out);
+    if (rc != RRT_OK) return rc;
+    return out->status;
+}
+
+extern "C" int rrt_plan(rrt_ctx *ctx, const rrt_query *query, uint32_t flags, rrt_result *out) {
+    if (!ctx || !query || !out) return fail(ctx, RRT_E_ARG, "rrt_plan: NULL");
+    if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_plan: call rrt_set_grid first");
+    int rc = ensure_single(ctx, query->n, flags);
+    if (rc != RRT_OK) return rc;
+    rc = rrt_batch_set_query(ctx->single, 0, query);
+    if (rc != RRT_OK) return rc;
+    return run_single(ctx, out);
+}
+
+extern "C" int rrt_plan_resume(rrt_ctx *ctx, const double *unitball, int32_t count, rrt_result *out) {
+    if (!ctx || !unitball || !out) return fail(ctx, RRT_E_ARG, "rrt_plan_resume: NULL");
+    rrt_batch *s = ctx->single;
+    if (!s || s->h_desc[0].status != ST_NEED_UB) return fail(ctx, RRT_E_ARG, "rrt_plan_resume: no query is waiting");
+    int rc = rrt_batch_set_unitball(s, 0, unitball, count, s->h_desc[0].i);
+    if (rc != RRT_OK) return rc;
+    return run_single(ctx, out);
+}
+
+extern "C" int rrt_plan_batch(rrt_ctx *ctx, int32_t Q, const rrt_query *queries, rrt_result *out) {
+    if (!ctx || !queries || !out || Q < 1) return fail(ctx, RRT_E_ARG, "rrt_plan_batch: bad argument");
+    int32_t n_cap = 0;
+    for (int q = 0; q < Q; ++q) n_cap = queries[q].n > n_cap ? queries[q].n : n_cap;
+    rrt_batch *b = nullptr;
+    int rc = rrt_batch_create(ctx, Q, n_cap, 0, &b);
+    if (rc != RRT_OK) return rc;
+    for (int q = 0; q < Q && rc == RRT_OK; ++q) rc = rrt_batch_set_query(b, q, &queries[q]);
+    if (rc == RRT_OK) rc = rrt_batch_launch(b);
+    if (rc == RRT_OK) rc = rrt_batch_sync(b);
+    int worst = RRT_OK;
+    for (int q = 0; q < Q && rc == RRT_OK; ++q) {
+        int r = rrt_batch_get_result(b, q, &out[q]);
+        if (r == RRT_E_HIP || r == RRT_E_ARG) rc = r;
+        else if (out[q].status != RRT_OK && worst == RRT_OK) worst = out[q].status;
+    }
+    rrt_batch_destroy(b);
+    return rc != RRT_OK ? rc : worst;
+}
+
+// ---- primitives ---------------------------------------------------------------------------
+
+extern "C" int rrt_prim_collisionfree(rrt_ctx *ctx, const int32_t *ab, int32_t m, uint8_t *out_free, int32_t *out_cells) {
+    if (!ctx || !ab || m < 0 || !out_free) return fail(ctx, RRT_E_ARG, "rrt_prim_collisionfree: bad argument");
+    if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_prim_collisionfree: no grid");
+    if (m == 0) return RRT_OK;
+    for (int k = 0; k < m; ++k)
+        if (ab[4 * k] < 0 || ab[4 * k] >= ctx->W || ab[4 * k + 2] < 0 || ab[4 * k + 2] >= ctx->W || ab[4 * k + 1] < 0 ||
+            ab[4 * k + 1] >= ctx->H || ab[4 * k + 3] < 0 || ab[4 * k + 3] >= ctx->H)
+            return fail(ctx, RRT_E_ARG, "rrt_prim_collisionfree: segment %d outside the grid", k);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int32_t *d_ab = nullptr, *d_cells = nullptr;
+    uint8_t *d_free = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_ab, (size_t)m * 4 * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&d_cells, (size_t)m * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&d_free, (size_t)m));
+    HIPCHK(ctx, hipMemcpyAsync(d_ab, ab, (size_t)m * 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const int waves_per_block = 4;
+    hipLaunchKernelGGL(prim_los_kernel, dim3((unsigned)((m + waves_per_block - 1) / waves_per_block)), dim3(64 * waves_per_block), 0,
+                       ctx->stream, ctx->og, ctx->H, d_ab, m, d_free, d_cells);
+    HIPCHK(ctx, hipMemcpyAsync(out_free, d_free, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_cells) HIPCHK(ctx, hipMemcpyAsync(out_cells, d_cells, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(d_ab));
+    HIPCHK(ctx, hipFree(d_cells));
+    HIPCHK(ctx, hipFree(d_free));
+    return RRT_OK;
+}
+
+extern "C" int rrt_prim_nearest_within(rrt_ctx *ctx, const int32_t *pts, int32_t j, const int32_t *xq, int32_t m, int64_t r2,
+                                       int32_t *out_nearest, int32_t *out_within_count, int64_t *out_within_idxsum) {
+    if (!ctx || !pts || !xq || j < 1 || m < 0 || !out_nearest) return fail(ctx, RRT_E_ARG, "rrt_prim_nearest_within: bad argument");
+    if ((long long)j > 64LL * CHUNK) return fail(ctx, RRT_E_UNSUPPORTED, "rrt_prim_nearest_within: j too large");
+    if (m == 0) return RRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> hp((size_t)((j + 3) & ~3), 0), hq((size_t)m);
+    for (int k = 0; k < j; ++k) {
+        if (pts[2 * k] < 0 || pts[2 * k] >= 2048 || pts[2 * k + 1] < 0 || pts[2 * k + 1] >= 2048)
+            return fail(ctx, RRT_E_ARG, "rrt_prim_nearest_within: node %d outside [0,2048)^2", k);
+        hp[(size_t)k] = ((uint32_t)pts[2 * k] & 0xffffu) | ((uint32_t)pts[2 * k + 1] << 16);
+    }
+    for (int k = 0; k < m; ++k) {
+        if (xq[2 * k] < 0 || xq[2 * k] >= 2048 || xq[2 * k + 1] < 0 || xq[2 * k + 1] >= 2048)
+            return fail(ctx, RRT_E_ARG, "rrt_prim_nearest_within: query %d outside [0,2048)^2", k);
+        hq[(size_t)k] = ((uint32_t)xq[2 * k] & 0xffffu) | ((uint32_t)xq[2 * k + 1] << 16);
+    }
+    uint32_t *d_p = nullptr, *d_q = nullptr;
+    int32_t *d_nn = nullptr, *d_cnt = nullptr;
+    unsigned long long *d_sum = nullptr;
+    uint2 *d_spill = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_sum, (size_t)m * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMalloc((void **)&d_spill, (size_t)m * (size_t)j * sizeof(uint2)));
+    HIPCHK(ctx, hipMalloc((void **)&d_p, hp.size() * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&d_q, hq.size() * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&d_nn, (size_t)m * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&d_cnt, (size_t)m * sizeof(int32_t)));
+    HIPCHK(ctx, hipMemcpyAsync(d_p, hp.data(), hp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_q, hq.data(), hq.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    const int64_t cap = 1 << 24;
+    const uint32_t r2c = (uint32_t)(r2 < 0 ? 0 : (r2 > cap ? cap : r2));
+    hipLaunchKernelGGL(prim_nn_kernel, dim3((unsigned)m), dim3(TPB), 0, ctx->stream, d_p, j, d_q, r2c, d_nn, d_cnt, d_sum, d_spill);
+    HIPCHK(ctx, hipMemcpyAsync(out_nearest, d_nn, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_within_count)
+        HIPCHK(ctx, hipMemcpyAsync(out_within_count, d_cnt, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_within_idxsum)
+        HIPCHK(ctx, hipMemcpyAsync(out_within_idxsum, d_sum, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(d_p));
+    HIPCHK(ctx, hipFree(d_q));
+    HIPCHK(ctx, hipFree(d_nn));
+    HIPCHK(ctx, hipFree(d_cnt));
+    HIPCHK(ctx, hipFree(d_sum));
+    HIPCHK(ctx, hipFree(d_spill));
+    return RRT_OK;
+}
+
+extern "C" int rrt_prim_sqrt_u32(rrt_ctx *ctx, uint32_t lo, uint32_t count, double *out) {
+    if (!ctx || !out) return fail(ctx, RRT_E_ARG, "rrt_prim_sqrt_u32: NULL");
+    if (count == 0) return RRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *d = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d, (size_t)count * sizeof(double)));
+    hipLaunchKernelGGL(prim_sqrt_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, lo, count, d);
+    HIPCHK(ctx, hipMemcpyAsync(out, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(d));
+    return RRT_OK;
+}
+
+extern "C" int rrt_prim_sqrt_f64(rrt_ctx *ctx, const double *in, uint32_t count, double *out) {
+    if (!ctx || !in || !out) return fail(ctx, RRT_E_ARG, "rrt_prim_sqrt_f64: NULL");
+    if (count == 0) return RRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_in, (size_t)count * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_out, (size_t)count * sizeof(double)));
+    HIPCHK(ctx, hipMemcpyAsync(d_in, in, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(prim_sqrt_f64_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, d_in, count, d_out);
+    HIPCHK(ctx, hipMemcpyAsync(out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(d_in));
+    HIPCHK(ctx, hipFree(d_out));
+    return RRT_OK;
+}

@@ -1,0 +1,93 @@
+"""Seeded fractal-noise occupancy grids (workload generator).
+
+Counterpart of the reference's ``perlin_occupancygrid`` (/root/reference/rrtplanner/oggen.py:7-45),
+which calls the third-party ``pyfastnoisesimd`` (pinned ==0.4.2 in the reference's
+requirements.txt:24, not vendored, unseeded).  The arithmetic of that package is not
+reproducible even inside the reference, so parity for grid *values* is unpinned
+(SURVEY.md 8(c)); what is kept is the contract of the function: fractal gradient noise,
+min-max normalised to [0,1], ``np.where(noise >= thresh, 0, 1)`` -> int64 ``(w,h)`` grid (or
+``(frames,w,h)``), 1 = obstacle, 0 = free.
+
+This generator is our own design: multi-octave lattice gradient noise with quintic
+fade, evaluated with numpy on the host, fully determined by ``seed``.
+"""
+import numpy as np
+
+__all__ = ["perlin_occupancygrid", "noise_field", "largest_free_component", "random_connected_pair"]
+
+
+def _fade(t):
+    return t * t * t * (t * (t * 6.0 - 15.0) + 10.0)
+
+
+def _gradient_noise3(shape, cell, rng):
+    """One octave of 3-D gradient noise on an integer lattice of spacing `cell` (float64)."""
+    f, w, h = shape
+    nz, nx, ny = int(np.ceil(f / cell)) + 2, int(np.ceil(w / cell)) + 2, int(np.ceil(h / cell)) + 2
+    g = rng.normal(size=(nz, nx, ny, 3))
+    g /= np.linalg.norm(g, axis=-1, keepdims=True)
+    z = np.arange(f) / cell
+    x = np.arange(w) / cell
+    y = np.arange(h) / cell
+    z0, x0, y0 = np.floor(z).astype(int), np.floor(x).astype(int), np.floor(y).astype(int)
+    fz, fx, fy = (z - z0)[:, None, None], (x - x0)[None, :, None], (y - y0)[None, None, :]
+    uz, ux, uy = _fade(fz), _fade(fx), _fade(fy)
+    out = np.zeros(shape)
+    for dz in (0, 1):
+        wz = uz if dz else 1.0 - uz
+        for dx in (0, 1):
+            wx = ux if dx else 1.0 - ux
+            for dy in (0, 1):
+                wy = uy if dy else 1.0 - uy
+                gg = g[(z0 + dz)[:, None, None], (x0 + dx)[None, :, None], (y0 + dy)[None, None, :]]
+                dot = gg[..., 0] * (fz - dz) + gg[..., 1] * (fx - dx) + gg[..., 2] * (fy - dy)
+                out += wz * wx * wy * dot
+    return out
+
+
+def noise_field(w: int, h: int, frames: int = None, seed: int = 0, base_cell: float = None, octaves: int = 4):
+    """Fractal gradient noise, float32, shape (w,h) or (frames,w,h)."""
+    rng = np.random.default_rng(seed)
+    f = 1 if frames is None else frames
+    cell = base_cell if base_cell is not None else max(8.0, min(w, h) / 6.0)
+    acc = np.zeros((f, w, h))
+    amp = 1.0
+    for _ in range(octaves):
+        acc += amp * _gradient_noise3((f, w, h), cell, rng)
+        amp *= 0.5
+        cell = max(2.0, cell / 2.0)
+    acc = acc.astype(np.float32)
+    return acc[0] if frames is None else acc
+
+
+def perlin_occupancygrid(w: int, h: int, thresh: float = 0.33, frames: int = None, seed: int = 1) -> np.ndarray:
+    """Same signature as the reference (oggen.py:7-9) plus ``seed``.
+
+    Returns an int64 grid, 1 = obstacle, 0 = free (oggen.py:40-45).
+    """
+    xynoise = noise_field(w, h, frames=frames, seed=seed)
+    xynoise = xynoise - xynoise.min()
+    xynoise = xynoise / (xynoise.max() - xynoise.min())
+    return np.where(xynoise >= thresh, 0, 1)
+
+
+def largest_free_component(og: np.ndarray) -> np.ndarray:
+    """Boolean mask of the largest 8-connected free region (start/goal must share one:
+    the reference faults in go2goal otherwise, rrt.py:317-318 / docs/getting-started.rst:36)."""
+    from scipy import ndimage
+
+    lab, k = ndimage.label(og == 0, structure=np.ones((3, 3), dtype=int))
+    if k == 0:
+        raise ValueError("occupancy grid has no free cell")
+    sizes = np.bincount(lab.ravel())
+    sizes[0] = 0
+    return lab == int(np.argmax(sizes))
+
+
+def random_connected_pair(og: np.ndarray, rnd_gen: np.random.Generator):
+    """Two free cells drawn like ``random_point_og`` (rrt.py:27-44) but restricted to the
+    largest free component."""
+    cells = np.argwhere(largest_free_component(og))
+    a = cells[rnd_gen.integers(low=0, high=cells.shape[0])]
+    b = cells[rnd_gen.integers(low=0, high=cells.shape[0])]
+    return a, b

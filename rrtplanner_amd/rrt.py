@@ -1,0 +1,286 @@
+"""Planner classes with the reference's surface, running the expansion loop on an MI355X.
+
+Mirrors rrtplanner/rrt.py of the reference: ``RRT`` (:50), ``RRTStandard`` (:375), ``RRTStar``
+(:453), ``RRTStarInformed`` (:562), ``r2norm`` (:11), ``random_point_og`` (:27).  ``plan()`` keeps
+the reference's contract -- ``(networkx.DiGraph, goal_vertex)`` with node attribute ``pt`` and edge
+attributes ``dist`` / ``cost`` (rrt.py:334-369) -- but its body is one call into the HIP engine
+(include/rrt_hip.h) instead of the Python loop.  The numpy ``Generator`` stays the source of
+randomness on the host, so the sample stream is the reference's bit for bit.
+
+There is no CPU fallback for ``plan()``: without the HIP library or a GPU it raises.
+Tie policy: nearest node / goal connection pick the lowest index among
+equal distance / cost (== a stable argsort in rrt.py:154 and :317).
+"""
+import math
+from typing import List, Tuple
+
+import networkx as nx
+import numpy as np
+from tqdm import tqdm
+
+from . import _ffi, hostprep
+from .hostprep import INT64_MIN
+
+__all__ = ["r2norm", "random_point_og", "RRT", "RRTStandard", "RRTStar", "RRTStarInformed"]
+
+
+def r2norm(x) -> float:
+    """2-norm of a (2,) vector (reference rrt.py:10-24)."""
+    return math.sqrt(x[0] * x[0] + x[1] * x[1])
+
+
+def random_point_og(og: np.ndarray, rnd_gen: np.random.Generator = None) -> np.ndarray:
+    """A uniformly random free cell of the occupancy grid (reference rrt.py:27-44)."""
+    free = np.argwhere(og == 0)
+    draw = np.random.randint if rnd_gen is None else rnd_gen.integers
+    return free[draw(low=0, high=free.shape[0])]
+
+
+class RRT(object):
+    """Base class: holds the grid, the sample budget and the RNG (reference rrt.py:50-86)."""
+
+    _ALG = None
+
+    def __init__(self, og: np.ndarray, n: int, costfn: callable = None, pbar: bool = True, seed: int = 0):
+        self.pbar = pbar
+        self.n = n
+        self.free = np.argwhere(og == 0)
+        self.og = og
+        self._custom_cost = costfn is not None
+        if costfn is None:
+
+            def costfn(vcosts: np.ndarray, points: np.ndarray, v: int, x: np.ndarray) -> float:
+                return vcosts[v] + r2norm(points[v] - x)
+
+        self.cost = costfn
+        self.not_a_point = [np.inf, np.inf]
+        self.not_a_dist = np.inf
+        self.rand_gen = np.random.default_rng(seed)
+        # device side, created on first plan()
+        self._ctx = None
+        self._grid_dirty = True
+        self.device_id = 0
+        self.last_stats = None
+
+    # ------------------------------------------------------------------ graph helpers
+    def route2gv(self, T: nx.DiGraph, gv) -> List[int]:
+        """Vertices of the shortest path root -> gv (reference rrt.py:87-107)."""
+        return nx.shortest_path(T, source=0, target=gv, weight="dist")
+
+    def vertices_as_ndarray(self, T: nx.DiGraph, path: list) -> np.ndarray:
+        """(M-1, 2, 2) array of consecutive path segment endpoints (reference rrt.py:109-129)."""
+        pts = [T.nodes[v]["pt"] for v in path]
+        return np.array([[pts[k], pts[k + 1]] for k in range(len(path) - 1)])
+
+    # ------------------------------------------------------------------ static primitives
+    @staticmethod
+    def near(points: np.ndarray, x: np.ndarray) -> np.ndarray:
+        """Indices of `points` by ascending distance to `x` (reference rrt.py:131-155);
+        equal distances keep index order (the canonical tie policy)."""
+        return np.argsort(np.linalg.norm(points - x, axis=1), kind="stable")
+
+    @staticmethod
+    def within(points: np.ndarray, x: np.ndarray, r: float) -> np.ndarray:
+        """Indices of `points` strictly closer than `r` to `x` (reference rrt.py:157-181)."""
+        d = points - x
+        d2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]
+        return np.atleast_1d(np.squeeze(np.argwhere(d2 < r * r)))
+
+    @staticmethod
+    def collisionfree(og, a, b) -> bool:
+        """True iff every cell of the reference's line walk a -> b (rrt.py:183-229) is free.
+        Uses the closed form of that walk (include/rrt_line.h)."""
+        x0, y0, x1, y1 = int(a[0]), int(a[1]), int(b[0]), int(b[1])
+        adx, ady = abs(x1 - x0), abs(y1 - y0)
+        sx = 1 if x0 < x1 else -1
+        sy = 1 if y0 < y1 else -1
+        major, minor = max(adx, ady), min(adx, ady)
+        k = np.arange(major + 1, dtype=np.int64)
+        m = (2 * minor * k + major) // (2 * major) if major > 0 else np.zeros(1, dtype=np.int64)
+        if adx >= ady:
+            xs, ys = x0 + sx * k, y0 + sy * m
+        else:
+            xs, ys = x0 + sx * m, y0 + sy * k
+        return not np.any(np.asarray(og)[xs, ys] != 0)
+
+    # ------------------------------------------------------------------ sampling / setters
+    def sample_all_free(self):
+        """One uniform free-space sample (reference rrt.py:231-240)."""
+        return self.free[self.rand_gen.choice(self.free.shape[0])]
+
+    def plan(self, xstart: np.ndarray, xgoal: np.ndarray):
+        raise NotImplementedError("This method is not implemented in the base class.")
+
+    def set_og(self, og_new: np.ndarray):
+        """New occupancy grid; free space is recomputed (reference rrt.py:261-272) and the grid
+        is re-uploaded to the device before the next plan()."""
+        self.og = og_new
+        self.free = np.argwhere(og_new == 0)
+        self._grid_dirty = True
+
+    def set_n(self, n: int):
+        self.n = n
+
+    # ------------------------------------------------------------------ device plumbing
+    def _device(self) -> "_ffi.Context":
+        if self._ctx is None:
+            self._ctx = _ffi.Context(self.device_id)
+            self._grid_dirty = True
+        if self._grid_dirty:
+            self._ctx.set_grid(hostprep.og_nonzero(self.og))
+            self._grid_dirty = False
+        return self._ctx
+
+    def _run(self, alg: int, xstart, xgoal, r_rewire=None, r_goal=None, logs=False):
+        """Drive one query through the C ABI.  Returns the ResultArrays (+ ellipse log inputs)."""
+        if self._custom_cost:
+            raise NotImplementedError(
+                "rrtplanner_amd runs the expansion loop on the GPU with the reference's default cost "
+                "(vcosts[v] + r2norm(points[v] - x), rrt.py:72-78); an arbitrary Python costfn cannot be "
+                "lowered to the device and there is no CPU fallback."
+            )
+        xs = hostprep.as_int_point(xstart, "xstart")
+        xg = hostprep.as_int_point(xgoal, "xgoal")
+        W, H = np.asarray(self.og).shape
+        for p, name in ((xs, "xstart"), (xg, "xgoal")):
+            if not (0 <= p[0] < W and 0 <= p[1] < H):
+                raise ValueError(f"{name}={p.tolist()} lies outside the {W}x{H} occupancy grid")
+        n = int(self.n)
+        ctx = self._device()
+        bitgen = self.rand_gen.bit_generator
+        state0 = bitgen.state
+        samples = hostprep.draw_free_samples(self.rand_gen, self.free, n)  # n draws, as rrt.py:421/502/696
+        Cm = None
+        if alg == _ffi.ALG_INFORMED:
+            try:
+                with np.errstate(all="ignore"):
+                    Cm = hostprep.rotation_to_world_frame(xs, xg)
+                if not np.all(np.isfinite(Cm)):
+                    Cm = None
+            except np.linalg.LinAlgError:
+                Cm = None
+        query, keep = _ffi.make_query(
+            alg, n, xs, xg, samples,
+            r2_rewire=hostprep.radius_threshold(r_rewire) if r_rewire is not None else 0,
+            goal_d2=hostprep.goal_threshold(r_goal) if r_goal is not None else 0,
+            Cmat=Cm,
+        )
+        rc, res = ctx.plan(query, n, logs=logs or alg == _ffi.ALG_INFORMED)
+        if rc == _ffi.RRT_NEED_UNITBALL:
+            # The tree reached the goal region at iteration i_switch: from there on the reference
+            # draws two uniforms per iteration instead of one free-space index (rrt.py:695-700).
+            # Rewind the generator to the state after exactly i_switch free draws, then draw the
+            # unit-ball stream for the remaining iterations and resume on the device.
+            i_sw = res.i_switch
+            bitgen.state = state0
+            hostprep.draw_free_samples(self.rand_gen, self.free, i_sw)
+            if Cm is None:
+                hostprep.rotation_to_world_frame(xs, xg)  # raises like rrt.py:609-612 would
+                raise np.linalg.LinAlgError("rotation_to_world_frame is not finite (xstart == xgoal?)")
+            ub = hostprep.draw_unitball(self.rand_gen, n - i_sw)
+            rc = ctx.plan_resume(ub, res)
+        if rc == _ffi.RRT_E_GOAL_UNREACHABLE:
+            # rrt.py:317-318: the next argsort entry is an unfilled row -> og[INT64_MIN, ...]
+            raise IndexError(f"index {INT64_MIN} is out of bounds for axis 0 with size {W}")
+        res.xs, res.xg, res.Cm = xs, xg, Cm
+        self.last_stats = {k: getattr(res, k) for k in ("j", "i_switch", "sum_j", "sum_cells_nn", "sum_near",
+                                                          "sum_cells_cand", "n_los_cand")}
+        return res
+
+    def _materialise(self, res) -> Tuple[nx.DiGraph, int]:
+        """points / vcosts / parents as the reference's plan() holds them after go2goal
+        (rrt.py:320-325), then the DiGraph of build_graph (rrt.py:334-369)."""
+        n, j, found = res.n, res.j, bool(res.found)
+        rows = n + 1 if found else n
+        live = j + 1 if found else j
+        points = np.full((rows, 2), INT64_MIN, dtype=np.int64)  # np.full(dtype=int, fill_value=inf) rows
+        vcosts = np.full((rows,), np.inf)
+        points[:live] = res.pts[:live]
+        vcosts[:live] = res.vcost[:live]
+        vgoal = int(res.vgoal)
+        if found:
+            points[n] = res.xg
+            vcosts[n] = vcosts[vgoal]
+        parents = {0: None}
+        par = res.parent[:live].tolist()
+        for child in range(1, live):
+            parents[child] = par[child]
+        return self.build_graph(vgoal, points, parents, vcosts), vgoal
+
+    def build_graph(self, vgoal, points, parents, vcosts) -> nx.DiGraph:
+        """DiGraph with every row of `points` as a node (`pt`) and one edge per tree link with
+        `dist` (float) and `cost` (np.float64) -- node order [vgoal, 0, 1, ...] and edge order of the
+        `parents` dict, as reference rrt.py:357-369."""
+        T = nx.DiGraph()
+        T.add_node(vgoal, pt=points[vgoal])
+        T.add_nodes_from((i, {"pt": p}) for i, p in enumerate(points))
+        kids = [c for c, p in parents.items() if p is not None]
+        if kids:
+            ch = np.asarray(kids, dtype=np.int64)
+            pa = np.asarray([parents[c] for c in kids], dtype=np.int64)
+            d = points[ch] - points[pa]
+            dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64)).tolist()
+            cost = vcosts[ch]
+            T.add_edges_from((int(p), int(c), {"dist": dd, "cost": cc}) for p, c, dd, cc in zip(pa, ch, dist, cost))
+        return T
+
+    def _plan(self, alg, xstart, xgoal, **kw):
+        bar = tqdm(total=self.n) if self.pbar else None
+        res = self._run(alg, xstart, xgoal, **kw)
+        out = self._materialise(res)
+        if bar is not None:
+            bar.update(self.n)
+            bar.close()
+        return res, out
+
+
+class RRTStandard(RRT):
+    """Plain RRT: the parent of a new node is its nearest node (reference rrt.py:375-447)."""
+
+    def __init__(self, og: np.ndarray, n: int, costfn: callable = None, pbar=True, seed: int = 0):
+        super().__init__(og, n, costfn=costfn, pbar=pbar, seed=seed)
+
+    def plan(self, xstart: np.ndarray, xgoal: np.ndarray) -> Tuple[nx.DiGraph, int]:
+        return self._plan(_ffi.ALG_STANDARD, xstart, xgoal)[1]
+
+
+class RRTStar(RRT):
+    """RRT with choose-parent inside r_rewire (reference rrt.py:453-556; its rewire step never
+    fires with the default cost)."""
+
+    def __init__(self, og: np.ndarray, n: int, r_rewire: float, costfn: callable = None, pbar=True, seed: int = 0):
+        super().__init__(og, n, costfn=costfn, pbar=pbar, seed=seed)
+        self.r_rewire = r_rewire
+
+    def plan(self, xstart: np.ndarray, xgoal: np.ndarray):
+        return self._plan(_ffi.ALG_STAR, xstart, xgoal, r_rewire=self.r_rewire)[1]
+
+
+class RRTStarInformed(RRT):
+    """RRT* that samples the start/goal ellipse once a node lies within r_goal of the goal
+    (reference rrt.py:562-758)."""
+
+    def __init__(self, og: np.ndarray, n: int, r_rewire: float, r_goal: float, costfn: callable = None,
+                 pbar: bool = True, seed: int = 0):
+        super().__init__(og, n, costfn=costfn, pbar=pbar, seed=seed)
+        self.r_rewire = r_rewire
+        self.r_goal = r_goal
+        self.ellipses = {}  # j -> (xcent, major axis, minor axis, angle in degrees), for plotting
+
+    def plan(self, xstart: np.ndarray, xgoal: np.ndarray):
+        res, out = self._plan(_ffi.ALG_INFORMED, xstart, xgoal, r_rewire=self.r_rewire, r_goal=self.r_goal)
+        self._record_ellipses(res)
+        return out
+
+    def _record_ellipses(self, res):
+        """self.ellipses[j] = get_ellipse_for_plt(...) of every ellipse iteration (rrt.py:701); a
+        later iteration with the same j overwrites the value, the key keeps its first position."""
+        i_sw, n = res.i_switch, res.n
+        if i_sw >= n:
+            return
+        jl = res.j_log[i_sw:n]
+        cl = res.cbest_log[i_sw:n]
+        last = np.flatnonzero(np.r_[jl[1:] != jl[:-1], True])  # last iteration of each run of equal j
+        xcent, maj, mnr, ang = hostprep.ellipse_plot_params(res.Cm, res.xs, res.xg, cl[last])
+        for k, a, b, g in zip(jl[last].tolist(), maj, mnr, ang):
+            self.ellipses[k] = (xcent.copy(), a, b, g)
