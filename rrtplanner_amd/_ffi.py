@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librrt_hip.so")
+LIB_PATH = os.environ.get("RRT_HIP_LIB", os.path.join(_HERE, "librrt_hip.so"))  # override: diagnostic builds only
 
 RRT_OK = 0
 RRT_NEED_UNITBALL = 1
@@ -29,7 +29,7 @@ SYMBOLS = (
     "rrt_ctx_create", "rrt_ctx_destroy", "rrt_last_error_string", "rrt_set_grid",
     "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
     "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_elapsed_ms",
-    "rrt_batch_get_result", "rrt_batch_result_block",
+    "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
     "rrt_plan", "rrt_plan_resume", "rrt_plan_batch",
     "rrt_prim_collisionfree", "rrt_prim_nearest_within", "rrt_prim_sqrt_u32", "rrt_prim_sqrt_f64",
 )
@@ -91,6 +91,7 @@ def lib():
             "rrt_batch_elapsed_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
             "rrt_batch_get_result": ([vp, i32, C.POINTER(Result)], C.c_int),
             "rrt_batch_result_block": ([vp, C.POINTER(vp), C.POINTER(i64)], C.c_int),
+            "rrt_batch_debug_cycles": ([vp, i32, C.POINTER(C.c_uint64 * 6)], C.c_int),
             "rrt_plan": ([vp, C.POINTER(Query), u32, C.POINTER(Result)], C.c_int),
             "rrt_plan_resume": ([vp, vp, i32, C.POINTER(Result)], C.c_int),
             "rrt_plan_batch": ([vp, i32, C.POINTER(Query), C.POINTER(Result)], C.c_int),
@@ -284,6 +285,11 @@ class Batch:
         rc = lib().rrt_batch_get_result(self._h, int(q), C.byref(res.c))
         _check(self.ctx.handle, rc, ok=(RRT_OK, RRT_E_GOAL_UNREACHABLE))
         return res
+
+    def debug_cycles(self, q):
+        out = (C.c_uint64 * 6)()
+        _check(self.ctx.handle, lib().rrt_batch_debug_cycles(self._h, int(q), C.byref(out)))
+        return list(out)
 
     def result_block(self):
         p, nbytes = C.c_void_p(), C.c_int64()

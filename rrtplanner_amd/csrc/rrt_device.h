@@ -13,10 +13,20 @@ constexpr int TPB = 1024;          // threads of one query workgroup (16 waves, 
 constexpr int NWAVE = TPB / 64;
 constexpr int CHUNK = TPB * 4;     // nodes per scan chunk: one 16-byte load per thread
 constexpr int MAX_LDS_CHUNKS = 8;  // node chunks cached in LDS (8 * 16 KiB = 128 KiB)
-constexpr int CANDCAP = 1536;      // near-set entries per LDS list (2 lists * 12 KiB)
+constexpr int WSLOTS = 3;          // near-set entries a lane prices in registers
+constexpr int WCAP = 64 * WSLOTS;  // near-set entries per wave in LDS (16 waves * 1.5 KiB)
 constexpr uint32_t NONE = 0xffffffffu;
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// explicit address spaces: LDS accesses must be ds_* instructions, never flat_* (a pointer
+// select between LDS and HBM silently degrades to flat loads with full waits)
+#define RRT_LDS __attribute__((address_space(3)))
+#define RRT_GLB __attribute__((address_space(1)))
+
+#define RRT_INF_BITS 0x7ff0000000000000ll
+__device__ __forceinline__ double f64_inf() { return __longlong_as_double(RRT_INF_BITS); }
 
 // Nodes and samples are packed int16x2: x in the low half, y in the high half.  Grids are
 // at most 2048 x 2048 on this path, so x,y < 2^11 and d2 < 2^23.
@@ -42,6 +52,17 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Wave-wide unsigned sum, result uniform in every lane (same DPP ladder, additive).
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Lexicographic wave minimum of (key, idx): smallest key, lowest idx among equal keys.
 __device__ __forceinline__ void wave_min_key_idx(uint32_t &key, uint32_t &idx) {
     uint32_t mk = wave_min_u32(key);
@@ -62,29 +83,52 @@ __device__ __forceinline__ void wave_min_f64_idx(double &c, uint32_t &idx) {
     idx = mi;
 }
 
+// (c1,i1) < (c2,i2) in (cost, index) order
+__device__ __forceinline__ bool key_lt(double c1, uint32_t i1, double c2, uint32_t i2) {
+    return c1 < c2 || (c1 == c2 && i1 < i2);
+}
+
 // r2norm of an integer difference (rrt.py:24): sqrt of an exact integer < 2^53.
 __device__ __forceinline__ double sqrt_u32(uint32_t d2) { return sqrt((double)d2); }
 
 // Line of sight a -> b (RRT.collisionfree, rrt.py:202-229) evaluated by one wavefront:
 // lane l tests cell k0+l of the closed-form walk (rrt_line.h); the ballot gives any-hit and
 // the first blocked cell.  `cells` = grid cells the reference's serial walk reads
-// before returning (first blocked cell + 1, or L+1).  Result uniform.
+// before returning (first blocked cell + 1, or L+1).  Result uniform.  Long segments keep four
+// 64-cell groups of loads in flight.
 __device__ __forceinline__ bool los_wave(const uint8_t *__restrict__ og, int H, uint32_t a, uint32_t b, int lane,
                                          int &cells) {
     rrt_line_t l = rrt_line_setup(ux(a), uy(a), ux(b), uy(b));
     const int L = l.major;
-    for (int k0 = 0; k0 <= L; k0 += 64) {
-        int k = k0 + lane;
+    if (L < 64) {
         bool occ = false;
-        if (k <= L) {
+        if (lane <= L) {
             int x, y;
-            rrt_line_cell(&l, k, &x, &y);
+            rrt_line_cell(&l, lane, &x, &y);
             occ = og[(size_t)x * H + y] != 0;
         }
         unsigned long long m = __ballot(occ);
-        if (m) {
-            cells = k0 + (int)__builtin_ctzll(m) + 1;
-            return false;
+        cells = m ? (int)__builtin_ctzll(m) + 1 : L + 1;
+        return m == 0;
+    }
+    for (int k0 = 0; k0 <= L; k0 += 256) {
+        uint8_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k = k0 + 64 * g + lane;
+            if (k <= L) {
+                int x, y;
+                rrt_line_cell(&l, k, &x, &y);
+                v[g] = og[(size_t)x * H + y];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            unsigned long long m = __ballot(v[g] != 0);
+            if (m) {
+                cells = k0 + 64 * g + (int)__builtin_ctzll(m) + 1;
+                return false;
+            }
         }
     }
     cells = L + 1;

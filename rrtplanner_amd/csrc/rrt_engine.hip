@@ -31,7 +31,7 @@ struct rrt_ctx {
 
 struct rrt_batch {
     rrt_ctx *ctx = nullptr;
-    int32_t Q = 0, n_cap = 0, node_stride = 0, bitmap_words = 0, lds_chunks = 1;
+    int32_t Q = 0, n_cap = 0, node_stride = 0, bitmap_words = 0, lds_chunks = 1, spill_stride = 0;
     int32_t gridW = 0, gridH = 0;
     uint32_t flags = 0;
     QDesc *d_desc = nullptr;
@@ -41,6 +41,8 @@ struct rrt_batch {
     int32_t *d_parent = nullptr, *d_nearest_log = nullptr, *d_j_log = nullptr;
     uint8_t *d_accept_log = nullptr;
     uint2 *d_spill = nullptr;
+    unsigned char *d_slab = nullptr;  // result slab: [vcost f64 | nodes u32 | parent i32], each [Q][node_stride]
+    size_t slab_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::vector<uint32_t> stage;  // host staging for packed samples
@@ -112,8 +114,8 @@ extern "C" int rrt_batch_destroy(rrt_batch *b) {
     if (!b) return RRT_OK;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ptrs[] = {b->d_desc,   b->d_samples,  b->d_nodes,     b->d_bitmap,      b->d_vcost, b->d_unitball,
-                    b->d_parent, b->d_spill,    b->d_cbest_log, b->d_nearest_log, b->d_j_log, b->d_accept_log};
+    void *ptrs[] = {b->d_desc,  b->d_samples,   b->d_slab,        b->d_bitmap, b->d_unitball,
+                    b->d_spill, b->d_cbest_log, b->d_nearest_log, b->d_j_log,  b->d_accept_log};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -139,6 +141,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->node_stride = ((n_cap + 4) + 3) & ~3;
     b->bitmap_words = (int32_t)(((size_t)ctx->W * ctx->H + 31) / 32);
     int chunks = (n_cap + 1 + CHUNK - 1) / CHUNK;
+    b->spill_stride = chunks * CHUNK;  // 256 overflow entries per wave and node chunk; also go2goal's cost array
     b->lds_chunks = chunks < 1 ? 1 : (chunks > MAX_LDS_CHUNKS ? MAX_LDS_CHUNKS : chunks);
     b->h_desc.assign((size_t)Q, QDesc{});
     for (auto &d : b->h_desc) d.status = ST_IDLE;
@@ -153,11 +156,13 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     } while (0)
     ALLOC(b->d_desc, q * sizeof(QDesc));
     ALLOC(b->d_samples, q * n_cap * sizeof(uint32_t));
-    ALLOC(b->d_nodes, q * b->node_stride * sizeof(uint32_t));
-    ALLOC(b->d_vcost, q * b->node_stride * sizeof(double));
-    ALLOC(b->d_parent, q * b->node_stride * sizeof(int32_t));
+    b->slab_bytes = q * b->node_stride * (sizeof(double) + sizeof(uint32_t) + sizeof(int32_t));
+    ALLOC(b->d_slab, b->slab_bytes);
+    b->d_vcost = reinterpret_cast<double *>(b->d_slab);
+    b->d_nodes = reinterpret_cast<uint32_t *>(b->d_slab + q * b->node_stride * sizeof(double));
+    b->d_parent = reinterpret_cast<int32_t *>(b->d_slab + q * b->node_stride * (sizeof(double) + sizeof(uint32_t)));
     ALLOC(b->d_bitmap, q * b->bitmap_words * sizeof(uint32_t));
-    ALLOC(b->d_spill, q * n_cap * sizeof(uint2));
+    ALLOC(b->d_spill, q * b->spill_stride * sizeof(uint2));
     if (flags & RRT_FLAG_LOGS) {
         ALLOC(b->d_nearest_log, q * n_cap * sizeof(int32_t));
         ALLOC(b->d_accept_log, q * n_cap * sizeof(uint8_t));
@@ -165,7 +170,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         ALLOC(b->d_j_log, q * n_cap * sizeof(int32_t));
     }
 #undef ALLOC
-    HIPCHK(ctx, hipMemsetAsync(b->d_nodes, 0, q * b->node_stride * sizeof(uint32_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(b->d_slab, 0, b->slab_bytes, ctx->stream));
     HIPCHK(ctx, hipEventCreate(&b->ev0));
     HIPCHK(ctx, hipEventCreate(&b->ev1));
     HIPCHK(ctx, hipMemcpyAsync(b->d_desc, b->h_desc.data(), q * sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream));
@@ -187,6 +192,7 @@ static void arm_desc(QDesc &d) {
     d.ub_offset = 0;
     d.ub_count = 0;
     d.sum_j = d.sum_cells_nn = d.sum_near = d.sum_cells_cand = d.n_los_cand = 0;
+    for (auto &c : d.cyc) c = 0;
 }
 
 extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu) {
@@ -280,12 +286,12 @@ static BatchView make_view(rrt_batch *b) {
     v.node_stride = b->node_stride;
     v.bitmap_words = b->bitmap_words;
     v.lds_chunks = b->lds_chunks;
+    v.spill_stride = b->spill_stride;
     return v;
 }
 
 static size_t expand_lds_bytes(int lds_chunks) {
-    return (size_t)lds_chunks * CHUNK * sizeof(uint32_t) + 2 * (size_t)CANDCAP * sizeof(uint2) + 2 * NWAVE * sizeof(CSlot) +
-           2 * NWAVE * sizeof(uint2) + 16;
+    return (size_t)lds_chunks * CHUNK * sizeof(uint32_t);  // dynamic part: the node cache (lists and slots are static LDS)
 }
 
 extern "C" int rrt_batch_launch(rrt_batch *b) {
@@ -296,7 +302,8 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     BatchView v = make_view(b);
     const size_t lds = expand_lds_bytes(b->lds_chunks);
-    if ((int)lds > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds, ctx->max_lds);
+    const size_t lds_static = (size_t)NWAVE * WCAP * sizeof(uint2) + 2 * NWAVE * (sizeof(Slot) + sizeof(BSlot));
+    if ((int)(lds + lds_static) > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds + lds_static, ctx->max_lds);
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rrt_expand_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
@@ -377,10 +384,16 @@ extern "C" int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out) {
     return d.status < 0 ? d.status : RRT_OK;
 }
 
+extern "C" int rrt_batch_debug_cycles(rrt_batch *b, int32_t q, uint64_t out[6]) {
+    if (!b || !out || q < 0 || q >= b->Q) return fail(nullptr, RRT_E_ARG, "rrt_batch_debug_cycles: bad argument");
+    for (int k = 0; k < 6; ++k) out[k] = b->h_desc[(size_t)q].cyc[k];
+    return RRT_OK;
+}
+
 extern "C" int rrt_batch_result_block(rrt_batch *b, void **dev_ptr, int64_t *bytes) {
     if (!b || !dev_ptr || !bytes) return fail(nullptr, RRT_E_ARG, "rrt_batch_result_block: NULL");
-    *dev_ptr = b->d_nodes;
-    *bytes = (int64_t)b->Q * b->node_stride * (int64_t)sizeof(uint32_t);
+    *dev_ptr = b->d_slab;
+    *bytes = (int64_t)b->slab_bytes;
     return RRT_OK;
 }
 
@@ -501,7 +514,8 @@ extern "C" int rrt_prim_nearest_within(rrt_ctx *ctx, const int32_t *pts, int32_t
     unsigned long long *d_sum = nullptr;
     uint2 *d_spill = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&d_sum, (size_t)m * sizeof(unsigned long long)));
-    HIPCHK(ctx, hipMalloc((void **)&d_spill, (size_t)m * (size_t)j * sizeof(uint2)));
+    const int spill_stride = ((j + CHUNK - 1) / CHUNK) * CHUNK;
+    HIPCHK(ctx, hipMalloc((void **)&d_spill, (size_t)m * (size_t)spill_stride * sizeof(uint2)));
     HIPCHK(ctx, hipMalloc((void **)&d_p, hp.size() * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc((void **)&d_q, hq.size() * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc((void **)&d_nn, (size_t)m * sizeof(int32_t)));
@@ -510,7 +524,7 @@ extern "C" int rrt_prim_nearest_within(rrt_ctx *ctx, const int32_t *pts, int32_t
     HIPCHK(ctx, hipMemcpyAsync(d_q, hq.data(), hq.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     const int64_t cap = 1 << 24;
     const uint32_t r2c = (uint32_t)(r2 < 0 ? 0 : (r2 > cap ? cap : r2));
-    hipLaunchKernelGGL(prim_nn_kernel, dim3((unsigned)m), dim3(TPB), 0, ctx->stream, d_p, j, d_q, r2c, d_nn, d_cnt, d_sum, d_spill);
+    hipLaunchKernelGGL(prim_nn_kernel, dim3((unsigned)m), dim3(TPB), 0, ctx->stream, d_p, j, d_q, r2c, d_nn, d_cnt, d_sum, d_spill, spill_stride);
     HIPCHK(ctx, hipMemcpyAsync(out_nearest, d_nn, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (out_within_count)
         HIPCHK(ctx, hipMemcpyAsync(out_within_count, d_cnt, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

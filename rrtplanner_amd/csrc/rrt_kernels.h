@@ -1,21 +1,25 @@
 // rrt_kernels.h -- the tree-expansion kernel: one persistent 1024-thread workgroup per query.
 //
 // Replaces the loops of rrtplanner/rrt.py:418-437 (RRTStandard), :498-548 (RRTStar),
-// :690-748 (RRTStarInformed) and go2goal (:311-332) of the reference.  Per iteration:
+// :690-748 (RRTStarInformed) and go2goal (:311-332) of the reference.  One barrier per iteration:
 //
-//   A  every thread scans its stripe of the live node array (LDS-resident chunks first,
-//      HBM/L2 chunks beyond) for the nearest node (packed key min) and, for RRT*, appends
-//      the nodes within r_rewire to an LDS near-set list         [near :150-155, within :176-181]
-//      -- one barrier --
-//   B  every wave folds the 16 per-wave minima, then tests the line of sight
-//      nearest -> sample with one ballot per 64 cells, and the `sampled` bitmap
-//                                                               [collisionfree :202-229, :425]
-//   C  RRT*: cost vcost[v] + sqrt(d2) of every near-set entry, workgroup minimum in
-//      (cost, index) order, line of sight of the winner, next-best on failure
-//                                                               [choose parent :511-521]
-//   D  thread 0 appends the node; the rewire scan (:531-546) is evaluated as its
-//      predicate only: cost(vn -> xnew) < vcosts[vn] is never true for the default cost
-//      (cost adds a non-negative distance), so it changes no state.
+//   A  every thread scans its stripe of the live node array (LDS-resident chunks, then HBM/L2
+//      chunks; 16-byte loads, next chunk prefetched) for the nearest node (packed key min); for RRT*
+//      each wave appends the nodes within r_rewire to its own LDS near-set list (no atomics)
+//                                                               [near :150-155, within :176-181]
+//      then, still before the barrier and speculatively, each wave
+//        - tests the line of sight  (its local nearest) -> sample       [collisionfree :202-229]
+//        - prices its near-set entries, cost = vcost[v] + sqrt(d2), finds its best and second best in
+//          (cost, index) order and tests the line of sight of its best  [choose parent :511-521]
+//      and publishes all of it in one 64-byte LDS slot
+//      -- barrier --
+//   B  every wave folds the 16 slots: global nearest (lowest index on ties), its line of sight and the
+//      `sampled` bitmap give the accept decision (:425); the cheapest passing wave-best that no untested
+//      entry can beat is the parent; only if an untested entry could still win do extra
+//      branch-and-bound rounds run (each with a barrier)
+//   D  thread 0 appends the node; the rewire scan (:531-546) is evaluated as its predicate only:
+//      cost(vn -> xnew) < vcosts[vn] is never true for the default cost (it adds a non-negative
+//      distance), so it changes no state.
 //
 // Results are bit-identical to the sequential reference under the canonical tie policy
 // (lowest index among equal distance / equal cost).
@@ -37,6 +41,7 @@ struct QDesc {
     int32_t status, i, j, nsoln, vbest_soln, vgoal, found, i_switch;
     double cmin_soln;
     unsigned long long sum_j, sum_cells_nn, sum_near, sum_cells_cand, n_los_cand;
+    unsigned long long cyc[6];  // diagnostic build (-DRRT_STAMPS): wave-0 cycles in scan / pre-barrier / barrier / B+C / D / go2goal
 };
 
 struct BatchView {
@@ -46,7 +51,7 @@ struct BatchView {
     double *vcost;            // [Q][node_stride]
     int32_t *parent;          // [Q][node_stride]
     uint32_t *bitmap;         // [Q][bitmap_words]  `sampled` set (rrt.py:407)
-    uint2 *spill;             // [Q][n_cap]         near-set overflow / go2goal costs
+    uint2 *spill;             // [Q][spill_stride]  per-wave near-set overflow / go2goal costs
     const double *unitball;   // [Q][2*n_cap] or null
     int32_t *nearest_log;     // optional logs [Q][n_cap]
     uint8_t *accept_log;
@@ -54,112 +59,154 @@ struct BatchView {
     int32_t *j_log;
     const uint8_t *og;        // (W,H) x-major occupancy, != 0 is obstacle
     int32_t W, H;
-    int32_t n_cap, node_stride, bitmap_words, lds_chunks;
+    int32_t n_cap, node_stride, bitmap_words, lds_chunks, spill_stride;
 };
 
-struct NearList {
-    uint2 *list;        // LDS [CANDCAP]
-    uint32_t *count;    // LDS counter
-    uint2 *spill;       // HBM overflow
+// Near set of one wave: every wave keeps the within-radius nodes of its own stripe in its own LDS
+// region (WCAP entries {idx, d2}, overflow to its own HBM region) and later prices them itself, so
+// the append needs no atomics: the fill count is a wave-uniform register.
+struct WaveList {
+    RRT_LDS u32x2 *list;  // LDS [WCAP] of this wave
+    u32x2 *spill;         // HBM overflow of this wave
 };
 
-// Wave-aggregated append of (idx, d2) for the lanes with `hit`.
-__device__ __forceinline__ void near_append(const NearList &nl, bool hit, uint32_t idx, uint32_t d2, int lane) {
-    unsigned long long m = __ballot(hit);
-    if (m == 0) return;
-    uint32_t base = 0;
-    int leader = (int)__builtin_ctzll(m);
-    if (lane == leader) base = atomicAdd(nl.count, (uint32_t)__builtin_popcountll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-    if (hit) {
-        uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (pos < (uint32_t)CANDCAP)
-            nl.list[pos] = make_uint2(idx, d2);
-        else
-            nl.spill[pos - CANDCAP] = make_uint2(idx, d2);
-    }
+__device__ __forceinline__ void wl_store(const WaveList &wl, uint32_t pos, uint32_t idx, uint32_t d2) {
+    u32x2 v = {idx, d2};
+    if (pos < (uint32_t)WCAP) wl.list[pos] = v;
+    if (pos >= (uint32_t)WCAP) wl.spill[pos - WCAP] = v;
+}
+
+// Append the lanes flagged in h0..h3 (element e of each lane's 4-node load).  Wave-uniform control flow.
+__device__ __forceinline__ void wl_append4(const WaveList &wl, uint32_t &wcnt, bool h0, bool h1, bool h2, bool h3,
+                                           uint32_t idx0, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, int lane) {
+    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+    if ((m0 | m1 | m2 | m3) == 0) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (h0) wl_store(wl, wcnt + (uint32_t)__builtin_popcountll(m0 & lt), idx0, d0);
+    wcnt += (uint32_t)__builtin_popcountll(m0);
+    if (h1) wl_store(wl, wcnt + (uint32_t)__builtin_popcountll(m1 & lt), idx0 + 1, d1);
+    wcnt += (uint32_t)__builtin_popcountll(m1);
+    if (h2) wl_store(wl, wcnt + (uint32_t)__builtin_popcountll(m2 & lt), idx0 + 2, d2);
+    wcnt += (uint32_t)__builtin_popcountll(m2);
+    if (h3) wl_store(wl, wcnt + (uint32_t)__builtin_popcountll(m3 & lt), idx0 + 3, d3);
+    wcnt += (uint32_t)__builtin_popcountll(m3);
 }
 
 template <bool STAR>
-__device__ __forceinline__ void eval4(uint4 v, uint32_t q, uint32_t tag0, uint32_t idx0, uint32_t r2, uint32_t &best,
-                                      const NearList &nl, int lane) {
+__device__ __forceinline__ void eval4(u32x4 v, uint32_t q, uint32_t tag0, uint32_t idx0, uint32_t r2, uint32_t &best,
+                                      const WaveList &wl, uint32_t &wcnt, int lane) {
     uint32_t d0 = dist2(v.x, q), d1 = dist2(v.y, q), d2 = dist2(v.z, q), d3 = dist2(v.w, q);
     best = min(best, (d0 << 8) + tag0);
     best = min(best, (d1 << 8) + tag0 + 1);
     best = min(best, (d2 << 8) + tag0 + 2);
     best = min(best, (d3 << 8) + tag0 + 3);
-    if (STAR) {
-        bool h0 = d0 < r2, h1 = d1 < r2, h2 = d2 < r2, h3 = d3 < r2;
-        if (__any(h0 | h1 | h2 | h3)) {
-            near_append(nl, h0, idx0, d0, lane);
-            near_append(nl, h1, idx0 + 1, d1, lane);
-            near_append(nl, h2, idx0 + 2, d2, lane);
-            near_append(nl, h3, idx0 + 3, d3, lane);
+    if (STAR) wl_append4(wl, wcnt, d0 < r2, d1 < r2, d2 < r2, d3 < r2, idx0, d0, d1, d2, d3, lane);
+}
+
+// One wave's publication for the iteration's barrier (64 bytes).
+struct Slot {
+    uint32_t d2n, vn;  // local nearest
+    uint32_t wcnt;     // near-set entries of this wave
+    uint32_t nn_los;   // line of sight local nearest -> sample: bit 31 = free, low bits = cells read
+    double vc_nn;      // vcost of the local nearest
+    double c1, c2;     // best / second best priced near-set entry of this wave, (cost, index) order
+    uint32_t i1, i2;
+    uint32_t los1;     // line of sight i1 -> sample: bit 31 = free, low bits = cells read
+    uint32_t pad[3];
+};
+static_assert(sizeof(Slot) == 64, "Slot must be 64 bytes");
+
+// Lane-local running best and second best in (cost, index) order.
+struct Top2 {
+    double c1, c2;
+    uint32_t i1, i2;
+    __device__ __forceinline__ void init() {
+        c1 = c2 = f64_inf();
+        i1 = i2 = NONE;
+    }
+    __device__ __forceinline__ void fold(double c, uint32_t i) {
+        if (key_lt(c, i, c1, i1)) {
+            c2 = c1;
+            i2 = i1;
+            c1 = c;
+            i1 = i;
+        } else if (key_lt(c, i, c2, i2)) {
+            c2 = c;
+            i2 = i;
         }
     }
-}
-
-// Workgroup minimum of (c, idx) through 16 LDS slots; every wave ends with the result.
-struct CSlot {
-    double c;
-    uint32_t idx;
-    uint32_t pad;
+    // wave-wide best and second best of all lanes' entries (uniform result)
+    __device__ __forceinline__ void wave_reduce() {
+        double bc = c1;
+        uint32_t bi = i1;
+        wave_min_f64_idx(bc, bi);
+        const bool own = (c1 == bc && i1 == bi);
+        double sc = own ? c2 : c1;
+        uint32_t si = own ? i2 : i1;
+        wave_min_f64_idx(sc, si);
+        c1 = bc;
+        i1 = bi;
+        c2 = sc;
+        i2 = si;
+    }
 };
 
-__device__ __forceinline__ void block_min_f64_idx(double &c, uint32_t &idx, CSlot *slots, int wave, int lane) {
-    wave_min_f64_idx(c, idx);
-    if (lane == 0) {
-        slots[wave].c = c;
-        slots[wave].idx = idx;
-    }
-    __syncthreads();
-    double cc = __longlong_as_double(0x7ff0000000000000ll);
-    uint32_t ii = NONE;
-    if (lane < NWAVE) {
-        cc = slots[lane].c;
-        ii = slots[lane].idx;
-    }
-    wave_min_f64_idx(cc, ii);
-    c = cc;
-    idx = ii;
-}
+// Workgroup exchange for the (rare) extra branch-and-bound rounds.
+struct BSlot {
+    double pc, uc;  // passing key of this round (or inf), best still-untested key (or inf)
+    uint32_t pi, ui;
+    uint32_t cells, tested;
+};
+
+#ifdef RRT_STAMPS
+#define STAMP(k)                                                \
+    do {                                                        \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        cyc[k] += now_ - tstamp;                                \
+        tstamp = now_;                                          \
+    } while (0)
+#else
+#define STAMP(k) \
+    do {         \
+    } while (0)
+#endif
 
 __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // node cache: lds_chunks * 16 KiB
+    __shared__ __attribute__((aligned(16))) u32x2 wlist_lds[NWAVE * WCAP];
+    __shared__ __attribute__((aligned(16))) Slot slots[2 * NWAVE];
+    __shared__ __attribute__((aligned(16))) BSlot bslots[2 * NWAVE];
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     const int q = (int)blockIdx.x;
     QDesc *D = bv.desc + q;
     const int32_t st0 = D->status;
     if (st0 != ST_RUNNING) return;  // uniform: finished, idle, or waiting for unit-ball data
 
-    // ---- LDS carve (every offset a multiple of 16) ----
-    uint32_t *nodes_lds = reinterpret_cast<uint32_t *>(smem);
-    size_t off = (size_t)bv.lds_chunks * CHUNK * sizeof(uint32_t);
-    uint2 *cand_lds = reinterpret_cast<uint2 *>(smem + off);
-    off += 2 * (size_t)CANDCAP * sizeof(uint2);
-    CSlot *cslots = reinterpret_cast<CSlot *>(smem + off);  // [2][NWAVE]
-    off += 2 * NWAVE * sizeof(CSlot);
-    uint2 *nnslots = reinterpret_cast<uint2 *>(smem + off);  // [2][NWAVE]
-    off += 2 * NWAVE * sizeof(uint2);
-    uint32_t *cand_cnt = reinterpret_cast<uint32_t *>(smem + off);  // [2]
+    RRT_LDS uint32_t *nodes_lds = (RRT_LDS uint32_t *)smem;
+    const RRT_LDS u32x4 *nodes_lds4 = (const RRT_LDS u32x4 *)smem;
 
     // ---- per-query views ----
     const int n = D->n, alg = D->alg;
     const bool star = alg >= 1, informed = alg == 2;
     const uint32_t *samples = bv.samples + (size_t)q * bv.n_cap;
     uint32_t *nodes_g = bv.nodes + (size_t)q * bv.node_stride;
+    const u32x4 *nodes_g4 = reinterpret_cast<const u32x4 *>(nodes_g);
     double *vcost = bv.vcost + (size_t)q * bv.node_stride;
     int32_t *parent = bv.parent + (size_t)q * bv.node_stride;
     uint32_t *bitmap = bv.bitmap + (size_t)q * bv.bitmap_words;
-    uint2 *spill = bv.spill + (size_t)q * bv.n_cap;
+    uint2 *spill = bv.spill + (size_t)q * bv.spill_stride;
     const double *ub = bv.unitball ? bv.unitball + (size_t)q * 2 * bv.n_cap : nullptr;
     const bool logs = bv.nearest_log != nullptr;
     const uint8_t *og = bv.og;
     const int W = bv.W, H = bv.H;
-    const int lds_nodes = bv.lds_chunks * CHUNK;
+    const int lds_chunks = bv.lds_chunks;
+    const int lds_nodes = lds_chunks * CHUNK;
     const uint32_t r2 = D->r2_rewire, goal_d2 = D->goal_d2;
     const uint32_t xs = pack_xy(D->xs[0], D->xs[1]), xg = pack_xy(D->xg[0], D->xg[1]);
     const int ub_offset = D->ub_offset, ub_count = D->ub_count;
+    // this wave's near-set list: LDS region + HBM overflow region (256 entries per node chunk)
+    const WaveList wl{(RRT_LDS u32x2 *)wlist_lds + wave * WCAP,
+                      reinterpret_cast<u32x2 *>(spill) + (size_t)wave * (size_t)(bv.spill_stride / NWAVE)};
 
     // ---- resumable state (uniform registers) ----
     int i = D->i, j = D->j;
@@ -169,6 +216,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
     unsigned long long sum_j = D->sum_j, sum_cells_nn = D->sum_cells_nn, sum_near = D->sum_near,
                        sum_cells_cand = D->sum_cells_cand, n_los_cand = D->n_los_cand;
     int status = ST_RUNNING;
+#ifdef RRT_STAMPS
+    unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
+    unsigned long long tstamp = __builtin_amdgcn_s_memtime();
+#endif
 
     // Informed: constants of the ellipse transform (rrt.py:590, :621)
     const double xc0 = ((double)(D->xs[0] + D->xg[0])) / 2.0, xc1 = ((double)(D->xs[1] + D->xg[1])) / 2.0;
@@ -179,11 +230,18 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
 
     // ---- prologue: stage the live nodes into LDS (fresh start: node 0 only) ----
     for (int k = t; k < j && k < lds_nodes; k += TPB) nodes_lds[k] = nodes_g[k];
-    if (t < 2) cand_cnt[t] = 0;
     __syncthreads();
 
-    uint32_t pend = 0;      // node j-1 when it was inserted by the previous iteration and may
+    uint32_t pend = 0;        // node j-1 when it was inserted by the previous iteration and may
     bool pend_valid = false;  // not be visible in LDS/HBM to the other waves yet
+    double pend_cost = 0.0;
+
+    // coordinates / cost of node v as seen by this iteration
+    auto node_xy = [&](uint32_t v) -> uint32_t {
+        if (pend_valid && (int)v == j - 1) return pend;
+        return ((int)v < lds_nodes) ? nodes_lds[v] : nodes_g[v];
+    };
+    auto node_cost = [&](uint32_t v) -> double { return (pend_valid && (int)v == j - 1) ? pend_cost : vcost[v]; };
 
     uint32_t s_next = (i < n) ? samples[i] : 0;
 
@@ -213,69 +271,151 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
             xq = pack_xy((int)vx, (int)vy);
             clog = c_ell;
         }
-        // `sampled` bitmap word of this cell: issue the load now, use it after the scan.  A bit set
+        // `sampled` bitmap word of this cell: issue the load now, use it after the barrier.  A bit set
         // by the previous iteration may not be visible yet; that case is the pending node below.
         const uint32_t cell = (uint32_t)ux(xq) * (uint32_t)H + (uint32_t)uy(xq);
         const uint32_t bm_word = bitmap[cell >> 5];
 
         // ---------------- A: scan the live nodes ----------------
-        NearList nl{cand_lds + par * CANDCAP, cand_cnt + par, spill};
         uint32_t best = NONE;
+        uint32_t wcnt = 0;                  // this wave's near-set fill (wave-uniform)
         const int nfull = (j - 1) / CHUNK;  // chunks that hold only committed nodes
-        for (int c = 0; c < nfull; ++c) {
-            uint4 v = (c < bv.lds_chunks) ? reinterpret_cast<const uint4 *>(nodes_lds)[c * TPB + t]
-                                          : reinterpret_cast<const uint4 *>(nodes_g)[c * TPB + t];
-            if (star)
-                eval4<true>(v, xq, (uint32_t)c << 2, (uint32_t)(c * CHUNK + 4 * t), r2, best, nl, lane);
-            else
-                eval4<false>(v, xq, (uint32_t)c << 2, (uint32_t)(c * CHUNK + 4 * t), r2, best, nl, lane);
+        const int nl = nfull < lds_chunks ? nfull : lds_chunks;
+        if (nl > 0) {
+            u32x4 cur = nodes_lds4[t];
+            for (int c = 0; c < nl; ++c) {
+                u32x4 nxt = cur;
+                if (c + 1 < nl) nxt = nodes_lds4[(c + 1) * TPB + t];
+                if (star)
+                    eval4<true>(cur, xq, (uint32_t)c << 2, (uint32_t)(c * CHUNK + 4 * t), r2, best, wl, wcnt, lane);
+                else
+                    eval4<false>(cur, xq, (uint32_t)c << 2, (uint32_t)(c * CHUNK + 4 * t), r2, best, wl, wcnt, lane);
+                cur = nxt;
+            }
+        }
+        if (nfull > nl) {
+            u32x4 cur = nodes_g4[nl * TPB + t];
+            for (int c = nl; c < nfull; ++c) {
+                u32x4 nxt = cur;
+                if (c + 1 < nfull) nxt = nodes_g4[(c + 1) * TPB + t];
+                if (star)
+                    eval4<true>(cur, xq, (uint32_t)c << 2, (uint32_t)(c * CHUNK + 4 * t), r2, best, wl, wcnt, lane);
+                else
+                    eval4<false>(cur, xq, (uint32_t)c << 2, (uint32_t)(c * CHUNK + 4 * t), r2, best, wl, wcnt, lane);
+                cur = nxt;
+            }
         }
         {  // tail chunk: masked, the pending node substituted from registers
             const int c = nfull;
             const int idx0 = c * CHUNK + 4 * t;
+            uint32_t dd[4] = {NONE, NONE, NONE, NONE};
             if (idx0 < j) {
-                uint4 v = (c < bv.lds_chunks) ? reinterpret_cast<const uint4 *>(nodes_lds)[c * TPB + t]
-                                              : reinterpret_cast<const uint4 *>(nodes_g)[c * TPB + t];
+                u32x4 v;
+                if (c < lds_chunks)
+                    v = nodes_lds4[c * TPB + t];
+                else
+                    v = nodes_g4[c * TPB + t];
                 uint32_t pv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int idx = idx0 + e;
                     if (idx < j) {
                         uint32_t p = (pend_valid && idx == j - 1) ? pend : pv[e];
-                        uint32_t d = dist2(p, xq);
-                        best = min(best, (d << 8) + ((uint32_t)c << 2) + (uint32_t)e);
-                        if (star && d < r2) {
-                            // tail hits are rare: plain per-lane append
-                            uint32_t pos = atomicAdd(nl.count, 1u);
-                            if (pos < (uint32_t)CANDCAP)
-                                nl.list[pos] = make_uint2((uint32_t)idx, d);
-                            else
-                                nl.spill[pos - CANDCAP] = make_uint2((uint32_t)idx, d);
-                        }
+                        dd[e] = dist2(p, xq);
+                        best = min(best, (dd[e] << 8) + ((uint32_t)c << 2) + (uint32_t)e);
                     }
                 }
             }
+            if (star)  // dd == NONE for masked elements: never below r2 (r2 <= 2^24)
+                wl_append4(wl, wcnt, dd[0] < r2, dd[1] < r2, dd[2] < r2, dd[3] < r2, (uint32_t)idx0, dd[0], dd[1], dd[2], dd[3], lane);
         }
+        uint32_t kd = best >> 8, ki;
         {
-            uint32_t kd = best >> 8, tag = best & 0xffu;
-            uint32_t ki = (best == NONE) ? NONE : (tag >> 2) * (uint32_t)CHUNK + 4u * (uint32_t)t + (tag & 3u);
+            const uint32_t tag = best & 0xffu;
+            ki = (best == NONE) ? NONE : (tag >> 2) * (uint32_t)CHUNK + 4u * (uint32_t)t + (tag & 3u);
             wave_min_key_idx(kd, ki);
-            if (lane == 0) nnslots[par * NWAVE + wave] = make_uint2(kd, ki);
         }
-        __syncthreads();  // barrier 1: per-wave minima, near-set list and last iteration's node are visible
+        STAMP(0);
 
-        // ---------------- B: nearest, line of sight, duplicate test ----------------
-        uint32_t d2n = NONE, vn = NONE;
-        if (lane < NWAVE) {
-            uint2 s = nnslots[par * NWAVE + lane];
-            d2n = s.x;
-            vn = s.y;
+        // ---------------- A': speculative work of this wave, overlapping the other waves' scans ----------------
+        // (a) local nearest: its cost and its line of sight to the sample
+        uint32_t my_nn_los = 0;
+        double my_vc_nn = 0.0;
+        if (ki != NONE) {
+            my_vc_nn = node_cost(ki);
+            int cells = 0;
+            const bool ok = los_wave(og, H, node_xy(ki), xq, lane, cells);
+            my_nn_los = (ok ? 0x80000000u : 0u) | (uint32_t)cells;
         }
+        // (b) price this wave's near-set entries, keep them in registers; best and second best
+        double ec[WSLOTS];
+        uint32_t ei[WSLOTS];
+        Top2 top;
+        top.init();
+        uint32_t my_los1 = 0;
+        if (star) {
+#pragma unroll
+            for (int s = 0; s < WSLOTS; ++s) {
+                const uint32_t c = (uint32_t)lane + 64u * (uint32_t)s;
+                ec[s] = f64_inf();
+                ei[s] = NONE;
+                if (c < wcnt && c < (uint32_t)WCAP) {
+                    const u32x2 e = wl.list[c];
+                    ei[s] = e.x;
+                    ec[s] = node_cost(e.x) + sqrt_u32(e.y);
+                    top.fold(ec[s], ei[s]);
+                }
+            }
+            for (uint32_t c = (uint32_t)WCAP + (uint32_t)lane; c < wcnt; c += 64) {  // overflow entries (huge radii)
+                const u32x2 e = wl.spill[c - WCAP];
+                top.fold(node_cost(e.x) + sqrt_u32(e.y), e.x);
+            }
+            top.wave_reduce();
+            if (top.i1 != NONE) {
+                int cc = 0;
+                const bool ok = los_wave(og, H, node_xy(top.i1), xq, lane, cc);  // rrt.py:519, speculative
+                my_los1 = (ok ? 0x80000000u : 0u) | (uint32_t)cc;
+            }
+        }
+        if (lane == 0) {
+            Slot s;
+            s.d2n = kd;
+            s.vn = ki;
+            s.wcnt = wcnt;
+            s.nn_los = my_nn_los;
+            s.vc_nn = my_vc_nn;
+            s.c1 = top.c1;
+            s.c2 = top.c2;
+            s.i1 = top.i1;
+            s.i2 = top.i2;
+            s.los1 = my_los1;
+            s.pad[0] = s.pad[1] = s.pad[2] = 0;
+            slots[par * NWAVE + wave] = s;
+        }
+        STAMP(1);
+        __syncthreads();  // the iteration's barrier: slots and last iteration's node are visible
+        STAMP(2);
+
+        // ---------------- B: fold the 16 slots ----------------
+        Slot s;
+        s.d2n = NONE;
+        s.vn = NONE;
+        s.wcnt = 0;
+        s.nn_los = 0;
+        s.vc_nn = 0.0;
+        s.c1 = s.c2 = f64_inf();
+        s.i1 = s.i2 = NONE;
+        s.los1 = 0;
+        if (lane < NWAVE) s = slots[par * NWAVE + lane];
+        uint32_t d2n = s.d2n, vn = s.vn;
         wave_min_key_idx(d2n, vn);
-        const uint32_t pn = (pend_valid && (int)vn == j - 1) ? pend : ((int)vn < lds_nodes ? nodes_lds[vn] : nodes_g[vn]);
-        const double vc_near = vcost[vn];
-        int cells = 0;
-        const bool nocoll = los_wave(og, H, pn, xq, lane, cells);
+        const int lw = (int)__builtin_ctzll(__ballot(s.d2n == d2n && s.vn == vn));  // winner's lane (a wave owns a node exclusively)
+        const uint32_t nn_los = (uint32_t)__builtin_amdgcn_readlane((int)s.nn_los, lw);
+        const unsigned long long vcb = (unsigned long long)__double_as_longlong(s.vc_nn);
+        const double vc_near = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(vcb >> 32), lw) << 32) |
+                                                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)vcb, lw)));
+        const bool nocoll = (nn_los >> 31) != 0;
+        const int cells = (int)(nn_los & 0x7fffffffu);
         const bool dup = ((bm_word >> (cell & 31)) & 1u) || (pend_valid && pend == xq);
         const bool acc = nocoll && !dup && j != n;  // rrt.py:425
         sum_j += (unsigned long long)j;
@@ -287,8 +427,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
             bv.j_log[(size_t)q * bv.n_cap + i] = j;
         }
         if (!acc) {
-            if (star && t == 0) cand_cnt[par] = 0;  // nobody reads this list
             pend_valid = false;
+            STAMP(3);
             continue;
         }
 
@@ -296,44 +436,85 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         uint32_t vbest = vn;
         double cbest = vc_near + sqrt_u32(d2n);
         if (star) {
-            const uint32_t m = cand_cnt[par];
-            sum_near += m;
             const double cnear = cbest;
-            double floor_c = -1.0;
-            uint32_t floor_i = 0;
-            int round = 0;
-            for (;;) {
-                double bc = __longlong_as_double(0x7ff0000000000000ll);
-                uint32_t bi = NONE;
-                for (uint32_t c = (uint32_t)t; c < m; c += TPB) {
-                    const uint2 e = (c < (uint32_t)CANDCAP) ? nl.list[c] : nl.spill[c - CANDCAP];
-                    const double cn = vcost[e.x] + sqrt_u32(e.y);
-                    if (!(cn < cnear)) continue;  // rrt.py:518, strict
-                    if (cn < floor_c || (cn == floor_c && e.x <= floor_i)) continue;  // already refused
-                    if (cn < bc || (cn == bc && e.x < bi)) {
-                        bc = cn;
-                        bi = e.x;
-                    }
-                }
-                block_min_f64_idx(bc, bi, cslots + (round & 1) * NWAVE, wave, lane);
-                ++round;
-                if (bi == NONE) break;  // nearest stays the parent
-                const uint32_t pb = (pend_valid && (int)bi == j - 1) ? pend
-                                                                     : ((int)bi < lds_nodes ? nodes_lds[bi] : nodes_g[bi]);
-                int cc = 0;
-                const bool ok = los_wave(og, H, pb, xq, lane, cc);  // rrt.py:519
-                sum_cells_cand += (unsigned long long)cc;
-                n_los_cand += 1;
-                if (ok) {
-                    vbest = bi;
-                    cbest = bc;
-                    break;
-                }
-                floor_c = bc;
-                floor_i = bi;
+            sum_near += (unsigned long long)wave_sum_u32(s.wcnt);
+            // round 0 was run speculatively by every wave before the barrier
+            const bool has1 = s.i1 != NONE && s.c1 < cnear;  // rrt.py:518, strict
+            double pc = (has1 && (s.los1 >> 31)) ? s.c1 : f64_inf();
+            uint32_t pi = (has1 && (s.los1 >> 31)) ? s.i1 : NONE;
+            const bool has2 = has1 && s.i2 != NONE && s.c2 < cnear;
+            double uc = has2 ? s.c2 : f64_inf();
+            uint32_t ui = has2 ? s.i2 : NONE;
+            n_los_cand += (unsigned long long)wave_sum_u32(has1 ? 1u : 0u);
+            sum_cells_cand += (unsigned long long)wave_sum_u32(has1 ? (s.los1 & 0x7fffffffu) : 0u);
+            wave_min_f64_idx(pc, pi);  // B: cheapest passing entry so far
+            wave_min_f64_idx(uc, ui);  // U: cheapest entry not tested yet
+            // this wave's own lower bound: everything below (lbc, lbi) in its list has been tested
+            double lbc = -1.0;
+            uint32_t lbi = 0;
+            if (top.i1 != NONE && top.c1 < cnear) {
+                lbc = top.c1;
+                lbi = top.i1 + 1;
             }
-            if (t == 0) cand_cnt[par] = 0;  // every thread has consumed the list (barrier inside block_min)
+            int round = 0;
+            while (ui != NONE && key_lt(uc, ui, pc, pi)) {  // an untested entry could still beat B: test more
+                Top2 tt;
+                tt.init();
+#pragma unroll
+                for (int k = 0; k < WSLOTS; ++k)
+                    if (ei[k] != NONE && ec[k] < cnear && !key_lt(ec[k], ei[k], lbc, lbi) && key_lt(ec[k], ei[k], pc, pi)) tt.fold(ec[k], ei[k]);
+                for (uint32_t c = (uint32_t)WCAP + (uint32_t)lane; c < wcnt; c += 64) {
+                    const u32x2 e = wl.spill[c - WCAP];
+                    const double cn = node_cost(e.x) + sqrt_u32(e.y);
+                    if (cn < cnear && !key_lt(cn, e.x, lbc, lbi) && key_lt(cn, e.x, pc, pi)) tt.fold(cn, e.x);
+                }
+                tt.wave_reduce();
+                BSlot bs;
+                bs.pc = f64_inf();
+                bs.pi = NONE;
+                bs.uc = tt.c2;
+                bs.ui = tt.i2;
+                bs.cells = 0;
+                bs.tested = 0;
+                if (tt.i1 != NONE) {
+                    int cc = 0;
+                    const bool ok = los_wave(og, H, node_xy(tt.i1), xq, lane, cc);
+                    if (ok) {
+                        bs.pc = tt.c1;
+                        bs.pi = tt.i1;
+                    }
+                    bs.cells = (uint32_t)cc;
+                    bs.tested = 1;
+                    lbc = tt.c1;
+                    lbi = tt.i1 + 1;
+                }
+                if (lane == 0) bslots[(round & 1) * NWAVE + wave] = bs;
+                __syncthreads();
+                BSlot r;
+                r.pc = r.uc = f64_inf();
+                r.pi = r.ui = NONE;
+                r.cells = r.tested = 0;
+                if (lane < NWAVE) r = bslots[(round & 1) * NWAVE + lane];
+                ++round;
+                n_los_cand += (unsigned long long)wave_sum_u32(r.tested);
+                sum_cells_cand += (unsigned long long)wave_sum_u32(r.cells);
+                double npc = r.pc;
+                uint32_t npi = r.pi;
+                wave_min_f64_idx(npc, npi);
+                if (key_lt(npc, npi, pc, pi)) {
+                    pc = npc;
+                    pi = npi;
+                }
+                uc = r.uc;
+                ui = r.ui;
+                wave_min_f64_idx(uc, ui);
+            }
+            if (pi != NONE) {
+                vbest = pi;
+                cbest = pc;
+            }
         }
+        STAMP(3);
 
         // ---------------- D: insert (rrt.py:524-529); rewire scan :531-546 is vacuous ----------------
         if (t == 0) {
@@ -352,54 +533,81 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
             }
         }
         pend = xq;
+        pend_cost = cbest;
         pend_valid = true;
         j++;
+        STAMP(4);
     }
 
     __syncthreads();  // last insert visible to every wave
 
     // ---------------- go2goal (rrt.py:311-332), only when the loop has finished ----------------
+    // costs[k] = vcost[k] + dist(k, goal) for every live node; the goal connects to the first node in
+    // stable (cost, index) order that has line of sight.  Branch and bound: every round each wave tests
+    // the cheapest untested node of its stripe; done when the cheapest passing node beats every
+    // untested one.
     int vgoal = 0, found = 0;
     if (status == ST_RUNNING) {
         double *costs = reinterpret_cast<double *>(spill);
         for (int k = t; k < j; k += TPB) costs[k] = vcost[k] + sqrt_u32(dist2(nodes_g[k], xg));  // rrt.py:313-314
         __syncthreads();
-        double floor_c = -1.0;
-        uint32_t floor_i = 0;
-        int round = 0;
         status = ST_DONE;
-        for (;;) {  // np.argsort(costs) order (stable), first node with line of sight (rrt.py:317-318)
-            double bc = __longlong_as_double(0x7ff0000000000000ll);
-            uint32_t bi = NONE;
+        double pc = f64_inf(), lbc = -1.0;
+        uint32_t pi = NONE, lbi = 0;
+        int round = 0;
+        for (;;) {
+            Top2 tt;
+            tt.init();
             for (int k = t; k < j; k += TPB) {
                 const double cn = costs[k];
-                if (cn < floor_c || (cn == floor_c && (uint32_t)k <= floor_i)) continue;
-                if (cn < bc || (cn == bc && (uint32_t)k < bi)) {
-                    bc = cn;
-                    bi = (uint32_t)k;
-                }
+                if (!key_lt(cn, (uint32_t)k, lbc, lbi) && key_lt(cn, (uint32_t)k, pc, pi)) tt.fold(cn, (uint32_t)k);
             }
-            block_min_f64_idx(bc, bi, cslots + (round & 1) * NWAVE, wave, lane);
+            tt.wave_reduce();
+            BSlot bs;
+            bs.pc = f64_inf();
+            bs.pi = NONE;
+            bs.uc = tt.c2;
+            bs.ui = tt.i2;
+            bs.cells = bs.tested = 0;
+            if (tt.i1 != NONE) {
+                int cc = 0;
+                if (los_wave(og, H, nodes_g[tt.i1], xg, lane, cc)) {  // rrt.py:318
+                    bs.pc = tt.c1;
+                    bs.pi = tt.i1;
+                }
+                lbc = tt.c1;
+                lbi = tt.i1 + 1;
+            }
+            if (lane == 0) bslots[(round & 1) * NWAVE + wave] = bs;
+            __syncthreads();
+            BSlot r;
+            r.pc = r.uc = f64_inf();
+            r.pi = r.ui = NONE;
+            if (lane < NWAVE) r = bslots[(round & 1) * NWAVE + lane];
             ++round;
-            if (bi == NONE) break;
-            int cc = 0;
-            if (los_wave(og, H, nodes_g[bi], xg, lane, cc)) {
-                found = 1;
-                vgoal = j;  // rrt.py:319
-                if (t == 0) {
-                    nodes_g[j] = xg;
-                    vcost[j] = bc;
-                    parent[j] = (int32_t)bi;
-                }
-                break;
+            double npc = r.pc, uc = r.uc;
+            uint32_t npi = r.pi, ui = r.ui;
+            wave_min_f64_idx(npc, npi);
+            wave_min_f64_idx(uc, ui);
+            if (key_lt(npc, npi, pc, pi)) {
+                pc = npc;
+                pi = npi;
             }
-            floor_c = bc;
-            floor_i = bi;
+            if (ui == NONE || !key_lt(uc, ui, pc, pi)) break;
         }
-        if (!found) {
+        if (pi != NONE) {
+            found = 1;
+            vgoal = j;  // rrt.py:319
+            if (t == 0) {
+                nodes_g[j] = xg;
+                vcost[j] = pc;
+                parent[j] = (int32_t)pi;
+            }
+        } else {
             if (j < n) status = ST_UNREACHABLE;  // the next argsort entry is a sentinel row (rrt.py:318 faults)
             vgoal = 0;                           // rrt.py:330-331
         }
+        STAMP(5);
     }
 
     if (t == 0) {
@@ -417,6 +625,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         D->sum_near = sum_near;
         D->sum_cells_cand = sum_cells_cand;
         D->n_los_cand = n_los_cand;
+#ifdef RRT_STAMPS
+        for (int k = 0; k < 6; ++k) D->cyc[k] = cyc[k];
+#endif
     }
 }
 

@@ -21,69 +21,58 @@ __global__ void prim_los_kernel(const uint8_t *og, int H, const int32_t *ab, int
 }
 
 // near()[0] and within() (rrt.py:150-155, :176-181) of one query point per workgroup: the scan
-// of rrt_expand_kernel phase A/B over nodes in HBM.
+// of rrt_expand_kernel phase A/B over nodes in HBM, with the same per-wave near-set lists.
 __global__ __launch_bounds__(TPB) void prim_nn_kernel(const uint32_t *nodes, int j, const uint32_t *queries, uint32_t r2,
                                                       int32_t *out_nearest, int32_t *out_count, unsigned long long *out_idxsum,
-                                                      uint2 *spill_all) {
-    __shared__ uint2 cand[CANDCAP];
-    __shared__ uint32_t cnt;
-    __shared__ uint2 nnslots[NWAVE];
+                                                      uint2 *spill_all, int spill_stride) {
+    __shared__ __attribute__((aligned(16))) u32x2 wlists[NWAVE * WCAP];
+    __shared__ uint4 nnslots[NWAVE];
     __shared__ unsigned long long idxsum;
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t xq = queries[blockIdx.x];
-    uint2 *spill = spill_all + (size_t)blockIdx.x * (size_t)j;
-    if (t == 0) {
-        cnt = 0;
-        idxsum = 0;
-    }
+    uint2 *spill = spill_all + (size_t)blockIdx.x * (size_t)spill_stride;
+    const WaveList wl{(RRT_LDS u32x2 *)wlists + wave * WCAP,
+                      reinterpret_cast<u32x2 *>(spill) + (size_t)wave * (size_t)(spill_stride / NWAVE)};
+    if (t == 0) idxsum = 0;
     __syncthreads();
-    NearList nl{cand, &cnt, spill};
-    uint32_t best = NONE;
+    uint32_t best = NONE, wcnt = 0;
     const int nfull = j / CHUNK;
     for (int c = 0; c < nfull; ++c) {
-        uint4 v = reinterpret_cast<const uint4 *>(nodes)[c * TPB + t];
-        eval4<true>(v, xq, (uint32_t)c << 2, (uint32_t)(c * CHUNK + 4 * t), r2, best, nl, lane);
+        u32x4 v = reinterpret_cast<const u32x4 *>(nodes)[c * TPB + t];
+        eval4<true>(v, xq, (uint32_t)c << 2, (uint32_t)(c * CHUNK + 4 * t), r2, best, wl, wcnt, lane);
     }
     {
         const int c = nfull, idx0 = c * CHUNK + 4 * t;
+        uint32_t dd[4] = {NONE, NONE, NONE, NONE};
         if (idx0 < j) {
-            uint4 v = reinterpret_cast<const uint4 *>(nodes)[c * TPB + t];
+            u32x4 v = reinterpret_cast<const u32x4 *>(nodes)[c * TPB + t];
             uint32_t pv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (idx0 + e < j) {
-                    uint32_t d = dist2(pv[e], xq);
-                    best = min(best, (d << 8) + ((uint32_t)c << 2) + (uint32_t)e);
-                    if (d < r2) {
-                        uint32_t pos = atomicAdd(nl.count, 1u);
-                        if (pos < (uint32_t)CANDCAP)
-                            nl.list[pos] = make_uint2((uint32_t)(idx0 + e), d);
-                        else
-                            nl.spill[pos - CANDCAP] = make_uint2((uint32_t)(idx0 + e), d);
-                    }
+                    dd[e] = dist2(pv[e], xq);
+                    best = min(best, (dd[e] << 8) + ((uint32_t)c << 2) + (uint32_t)e);
                 }
             }
         }
+        wl_append4(wl, wcnt, dd[0] < r2, dd[1] < r2, dd[2] < r2, dd[3] < r2, (uint32_t)idx0, dd[0], dd[1], dd[2], dd[3], lane);
     }
     uint32_t kd = best >> 8, tag = best & 0xffu;
     uint32_t ki = (best == NONE) ? NONE : (tag >> 2) * (uint32_t)CHUNK + 4u * (uint32_t)t + (tag & 3u);
     wave_min_key_idx(kd, ki);
-    if (lane == 0) nnslots[wave] = make_uint2(kd, ki);
+    if (lane == 0) nnslots[wave] = make_uint4(kd, ki, wcnt, 0u);
+    unsigned long long s = 0;
+    for (uint32_t c = (uint32_t)lane; c < wcnt; c += 64) s += (c < (uint32_t)WCAP) ? wl.list[c].x : wl.spill[c - WCAP].x;
+    if (s) atomicAdd(&idxsum, s);
     __syncthreads();
-    uint32_t d2n = NONE, vn = NONE;
+    uint32_t d2n = NONE, vn = NONE, m = 0;
     if (lane < NWAVE) {
         d2n = nnslots[lane].x;
         vn = nnslots[lane].y;
+        m = nnslots[lane].z;
     }
     wave_min_key_idx(d2n, vn);
-    const uint32_t m = cnt;
-    unsigned long long s = 0;
-    for (uint32_t c = (uint32_t)t; c < m; c += TPB) {
-        const uint2 e = (c < (uint32_t)CANDCAP) ? cand[c] : spill[c - CANDCAP];
-        s += e.x;
-    }
-    if (s) atomicAdd(&idxsum, s);
-    __syncthreads();
+    m = wave_sum_u32(m);
     if (t == 0) {
         out_nearest[blockIdx.x] = (int32_t)vn;
         out_count[blockIdx.x] = (int32_t)m;

@@ -1,0 +1,283 @@
+"""GPU: the HIP path through the C ABI against the CPU oracle and the reference's golden vectors.
+
+Bit-exact for tree topology, node coordinates, collision decisions and edge costs (f64).  Everything
+here calls librrt_hip.so; the oracle is only the checker."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+import orchelp
+from rrtplanner_amd import _ffi, hostprep
+from rrtplanner_amd import rrt as amd
+from rrtplanner_amd.oggen import perlin_occupancygrid, random_connected_pair
+
+pytestmark = pytest.mark.gpu
+
+P = orchelp.golden("primitives.npz").z
+GA = orchelp.golden("plans_A.npz")
+GS = orchelp.golden("special_A.npz")
+
+
+# ------------------------------------------------------------------------------- primitives
+def test_sqrt_of_every_squared_distance_is_correctly_rounded(gpu_ctx):
+    """r2norm radicands on a 2048x2048 grid are the integers below 2^23: check them ALL against the
+    host's correctly rounded sqrt (the reference's math.sqrt)."""
+    step = 1 << 22
+    for lo in range(0, 1 << 23, step):
+        got = gpu_ctx.prim_sqrt_u32(lo, step)
+        want = np.sqrt(np.arange(lo, lo + step, dtype=np.float64))
+        assert np.array_equal(got, want)
+    got = gpu_ctx.prim_sqrt_u32((1 << 24) - 4096, 4096)
+    assert np.array_equal(got, np.sqrt(np.arange((1 << 24) - 4096, 1 << 24, dtype=np.float64)))
+
+
+def test_sqrt_f64_random(gpu_ctx):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(0, 1e7, 2_000_000), rng.uniform(0, 1, 500_000) ** 8 * 1e12,
+                        np.array([0.0, 1.0, 2.0, 0.25, 1e-300, 1e300])])
+    assert np.array_equal(gpu_ctx.prim_sqrt_f64(x), np.sqrt(x))
+
+
+def test_collisionfree_all_pairs_12x12(gpu_ctx):
+    g = P["cf12_grid"]
+    gpu_ctx.set_grid(g)
+    ab = np.array([(a, b, c, d) for a in range(12) for b in range(12) for c in range(12) for d in range(12)], dtype=np.int32)
+    free, cells = gpu_ctx.prim_collisionfree(ab)
+    assert np.array_equal(free, P["cf12_free"].astype(bool))
+    for k in range(0, len(ab), 97):
+        ok, c = oracle.collisionfree(g, ab[k, :2], ab[k, 2:])
+        assert ok == free[k] and c == cells[k]
+
+
+def test_collisionfree_noise_and_long_segments(gpu_ctx):
+    g = GA.grid("noise200")
+    gpu_ctx.set_grid(g)
+    free, cells = gpu_ctx.prim_collisionfree(P["cf200_seg"])
+    assert np.array_equal(free, P["cf200_free"].astype(bool))
+    # 2048 x 2048 noise grid, long random segments, against the oracle (decision and cell count)
+    big = (perlin_occupancygrid(2048, 2048, seed=3) != 0).astype(np.uint8)
+    gpu_ctx.set_grid(big)
+    rng = np.random.default_rng(5)
+    seg = rng.integers(0, 2048, size=(20000, 4)).astype(np.int32)
+    seg[:2000, 2:] = np.clip(seg[:2000, :2] + rng.integers(-70, 70, size=(2000, 2)), 0, 2047)
+    free, cells = gpu_ctx.prim_collisionfree(seg)
+    for k in range(len(seg)):
+        ok, c = oracle.collisionfree(big, seg[k, :2], seg[k, 2:])
+        assert ok == free[k] and c == cells[k], seg[k]
+    # empty grid: cells == walk length (closed form covers the whole walk)
+    gpu_ctx.set_grid(np.zeros((2048, 2048), dtype=np.uint8))
+    free, cells = gpu_ctx.prim_collisionfree(P["walk_seg"])
+    assert free.all()
+    assert np.array_equal(cells, np.diff(P["walk_offs"]).astype(np.int32))
+
+
+def test_nearest_and_within_fixture(gpu_ctx):
+    pts, xq = P["within_pts"], P["within_xq"]
+    for k, r in enumerate(P["within_r"]):
+        R = hostprep.radius_threshold(int(r) if float(r).is_integer() else float(r))
+        nn, cnt, isum = gpu_ctx.prim_nearest_within(pts, xq, R)
+        assert nn.tolist() == P["near_stable"].tolist()
+        assert cnt.tolist() == P[f"within_cnt_{k}"].tolist()
+        assert isum.tolist() == P[f"within_sum_{k}"].tolist()
+
+
+@pytest.mark.parametrize("j", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8192, 50000, 100000])
+def test_nearest_and_within_sizes_with_ties(gpu_ctx, j):
+    rng = np.random.default_rng(j)
+    side = 64 if j < 5000 else 2048  # small side => many equidistant nodes
+    pts = rng.integers(0, side, size=(j, 2)).astype(np.int32)
+    xq = rng.integers(0, side, size=(24, 2)).astype(np.int32)
+    xq[:4] = pts[rng.integers(0, j, size=4)]  # distance 0
+    for R in (0, 1, 64 * 64, 1 << 24):
+        nn, cnt, isum = gpu_ctx.prim_nearest_within(pts, xq, R)
+        for k, x in enumerate(xq):
+            assert nn[k] == oracle.nearest(pts, x)
+            w = oracle.within(pts, x, R)
+            assert cnt[k] == len(w) and isum[k] == int(w.astype(np.int64).sum())
+
+
+# ------------------------------------------------------------------------------- full plans vs golden
+def _run_case(G, meta, planner=None):
+    og = G.grid(meta["grid"]).astype(np.int64)
+    p = planner or orchelp.make_planner(amd, meta, og)
+    xs, xg = np.array(meta["xstart"]), np.array(meta["xgoal"])
+    if meta.get("raises") == "IndexError":
+        with pytest.raises(IndexError):
+            p.plan(xs, xg)
+        assert orchelp.rng_state_tuple(p.rand_gen) == meta["rng_state"]
+        return p
+    T, gv = p.plan(xs, xg)
+    orchelp.check_plan_against_golden(G, meta, p, T, gv)
+    return p
+
+
+@pytest.mark.parametrize("meta", GA.manifest, ids=[m["id"] for m in GA.manifest])
+def test_plan_policy_A(meta):
+    _run_case(GA, meta)
+
+
+@pytest.mark.parametrize("meta", [m for m in GS.manifest if "chain" not in m], ids=lambda m: m["id"])
+def test_plan_special_cases(meta):
+    _run_case(GS, meta)
+
+
+@pytest.mark.parametrize("tag", ["std", "star", "inf"])
+def test_replan_chain_rng_continues_and_set_og(tag):
+    chain = sorted([m for m in GS.manifest if m.get("chain") == f"replan__{tag}"], key=lambda m: m["step"])
+    p = None
+    for m in chain:
+        og = GS.grid(m["grid"]).astype(np.int64)
+        if p is None:
+            p = orchelp.make_planner(amd, m, og)
+        elif m["step"] == 2:
+            p.set_og(og)
+        _run_case(GS, m, planner=p)
+
+
+# ------------------------------------------------------------------------------- device vs oracle, larger
+def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None):
+    rng = np.random.default_rng(seed)
+    free = np.argwhere(og8 == 0)
+    samples = hostprep.draw_free_samples(rng, free, n)
+    r2 = hostprep.radius_threshold(r_rewire) if r_rewire is not None else 0
+    gd2 = hostprep.goal_threshold(r_goal) if r_goal is not None else 0
+    Cm = hostprep.rotation_to_world_frame(np.asarray(xs, dtype=np.int64), np.asarray(xg, dtype=np.int64)) if alg == 2 else None
+    q, keep = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2, goal_d2=gd2, Cmat=Cm)
+    rc, res = ctx.plan(q, n, logs=True)
+    st, ro = oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=r2, r_goal=r_goal or 0.0, Cmat=Cm)
+    ub = None
+    if rc == _ffi.RRT_NEED_UNITBALL:
+        assert st == oracle.ORC_NEED_UNITBALL and res.i_switch == ro.i_switch
+        ub = hostprep.draw_unitball(rng, n - res.i_switch)
+        rc = ctx.plan_resume(ub, res)
+        st, ro = oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=r2, r_goal=r_goal, unitball=ub, ub_offset=res.i_switch, Cmat=Cm)
+    assert rc == st
+    assert res.j == ro.j and res.found == ro.found and res.vgoal == ro.vgoal and res.i_switch == ro.i_switch
+    live = ro.j + (1 if ro.found else 0)
+    assert np.array_equal(res.nearest_log, ro.nearest_log)
+    assert np.array_equal(res.accept_log, ro.accept_log)
+    assert np.array_equal(res.j_log, ro.jlog)
+    assert np.array_equal(res.pts[:live], ro.pts[:live])
+    assert np.array_equal(res.parent[:live], ro.parent[:live])
+    assert np.array_equal(res.vcost[:live], ro.vcost[:live])  # bit-exact f64 (tolerance stated by the north star: 1e-6)
+    assert np.array_equal(res.cbest_log, ro.cbest_log, equal_nan=True)
+    assert res.sum_j == ro.sum_j and res.sum_cells_nn == ro.sum_cells_nn and res.sum_near == ro.sum_near
+    return res, ro
+
+
+@pytest.mark.parametrize("alg,rr,rg", [(0, None, None), (1, 64, None), (2, 64, 12)])
+def test_device_vs_oracle_1024_n6000(gpu_ctx, alg, rr, rg):
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    xs, xg = random_connected_pair(og, np.random.default_rng(7))
+    _oracle_vs_device(gpu_ctx, og8, alg, 6000, 0, xs, xg, rr, rg)
+
+
+def test_device_vs_oracle_beyond_lds_capacity(gpu_ctx):
+    """n = 40000 > 32768 LDS-resident nodes: the scan crosses from LDS chunks into HBM chunks."""
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    xs, xg = random_connected_pair(og, np.random.default_rng(7))
+    _oracle_vs_device(gpu_ctx, og8, 1, 40000, 0, xs, xg, 64, None)
+
+
+def test_device_vs_oracle_near_set_spills(gpu_ctx):
+    """r_rewire far beyond the grid: the near set is the whole tree and overflows the LDS list."""
+    og = perlin_occupancygrid(256, 256, seed=4)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    xs, xg = random_connected_pair(og, np.random.default_rng(1))
+    _oracle_vs_device(gpu_ctx, og8, 1, 5000, 3, xs, xg, 1e6, None)
+
+
+def test_batch_of_queries_matches_single_queries(gpu_ctx):
+    og = perlin_occupancygrid(512, 512, seed=2)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    sg = np.random.default_rng(7)
+    Q, n = 12, 3000
+    b = _ffi.Batch(gpu_ctx, Q, n)
+    keep, refs = [], []
+    for q in range(Q):
+        xs, xg = random_connected_pair(og, sg)
+        samples = hostprep.draw_free_samples(np.random.default_rng(q), free, n)
+        alg = q % 2
+        qu, k = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(48))
+        keep.append(k)
+        b.set_query(q, qu)
+        refs.append(oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=hostprep.radius_threshold(48)))
+    for rep in range(2):  # second pass: rearm keeps the inputs resident
+        b.launch()
+        b.sync()
+        assert b.elapsed_ms() > 0
+        for q in range(Q):
+            res = b.get_result(q)
+            st, ro = refs[q]
+            live = ro.j + (1 if ro.found else 0)
+            assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal
+            assert np.array_equal(res.pts[:live], ro.pts[:live])
+            assert np.array_equal(res.parent[:live], ro.parent[:live])
+            assert np.array_equal(res.vcost[:live], ro.vcost[:live])
+        b.rearm()
+    b.close()
+
+
+# ------------------------------------------------------------------------------- properties at full size
+def test_full_size_properties_rrtstar_1024_n50000():
+    """BASELINE config 2 (RRT*, 1024x1024, n=50000): size-independent properties of the result --
+    every edge has a clear line of sight, cost[child] == cost[parent] + dist (no rewire ever fires),
+    no duplicate nodes, every node is a free cell, parents precede children, the path reaches the goal."""
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    xs, xg = random_connected_pair(og, np.random.default_rng(7))
+    n = 50000
+    p = amd.RRTStar(og, n, 64, pbar=False, seed=0)
+    res = p._run(_ffi.ALG_STAR, xs, xg, r_rewire=64)
+    j, live = res.j, res.j + 1
+    assert res.found and res.vgoal == j
+    pts, par, vc = res.pts[:live].astype(np.int64), res.parent[:live].astype(np.int64), res.vcost[:live]
+    assert par[0] == -1 and np.all(par[1:] >= 0) and np.all(par[1:] < np.arange(1, live))
+    assert np.all(og[pts[:, 0], pts[:, 1]] == 0)
+    assert len({(a, b) for a, b in pts[:j].tolist()}) >= j - 1  # only xstart may repeat once (rrt.py:425)
+    d = pts[1:] - pts[par[1:]]
+    dist = np.sqrt((d * d).sum(1).astype(np.float64))
+    assert np.array_equal(vc[1:], vc[par[1:]] + dist)
+    og8 = oracle.og_u8(og)
+    ctx = p._device()
+    free, _ = ctx.prim_collisionfree(np.concatenate([pts[par[1:]], pts[1:]], axis=1).astype(np.int32))
+    assert free.all()
+    # accepted nodes are exactly a subsequence of the sample stream
+    samples = hostprep.draw_free_samples(np.random.default_rng(0), np.argwhere(og == 0), n)
+    it = iter(map(tuple, samples.tolist()))
+    assert all(any(s == tuple(v) for s in it) for v in pts[1:j].tolist())
+    T, gv = p._materialise(res)
+    path = p.route2gv(T, gv)
+    assert path[0] == 0 and path[-1] == gv and np.array_equal(T.nodes[gv]["pt"], xg)
+    # and the oracle agrees on the whole tree
+    st, ro = oracle.plan(og8, n, 1, xs, xg, samples, r2_rewire=hostprep.radius_threshold(64), logs=False)
+    assert ro.j == j and np.array_equal(ro.pts[:live], res.pts[:live]) and np.array_equal(ro.parent[:live], res.parent[:live])
+    assert np.array_equal(ro.vcost[:live], vc)
+
+
+def test_missing_grid_and_bad_arguments_fail_loudly():
+    ctx = _ffi.Context(0)
+    with pytest.raises(_ffi.RRTError):
+        _ffi.Batch(ctx, 1, 10)  # no grid yet
+    ctx.set_grid(np.zeros((8, 8), dtype=np.uint8))
+    q, keep = _ffi.make_query(0, 4, (0, 0), (9, 9), np.zeros((4, 2), dtype=np.int32))
+    with pytest.raises(_ffi.RRTError):
+        ctx.plan(q, 4)  # goal outside the grid
+    with pytest.raises(_ffi.RRTError):
+        ctx.set_grid(np.zeros((4096, 8), dtype=np.uint8))
+    ctx.close()
+
+
+def test_custom_costfn_is_rejected_not_emulated():
+    og = np.zeros((20, 20), dtype=int)
+    p = amd.RRTStar(og, 10, 5, costfn=lambda vc, pts, v, x: vc[v] + 1.0, pbar=False)
+    with pytest.raises(NotImplementedError):
+        p.plan(np.array([1, 1]), np.array([5, 5]))

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader cycles of rrt_expand_kernel (wave 0 of query 0) from the stamped build.
+
+    make -C rrtplanner_amd/csrc ../librrt_hip_stamps.so
+    RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so python tools/stamps.py [--n 50000] [--alg 1] [--queries 1]
+
+Never quote the stamped build's run time; read the shares."""
+import argparse, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rrtplanner_amd import _ffi, hostprep
+from rrtplanner_amd.oggen import perlin_occupancygrid, random_connected_pair
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=50000)
+ap.add_argument("--alg", type=int, default=1)
+ap.add_argument("--queries", type=int, default=1)
+ap.add_argument("--grid", type=int, default=1024)
+a = ap.parse_args()
+og = perlin_occupancygrid(a.grid, a.grid, seed=1)
+free = np.argwhere(og == 0)
+ctx = _ffi.Context(0); ctx.set_grid(hostprep.og_nonzero(og))
+b = _ffi.Batch(ctx, a.queries, a.n)
+sg = np.random.default_rng(7); keep = []
+for q in range(a.queries):
+    xs, xg = random_connected_pair(og, sg)
+    s = hostprep.draw_free_samples(np.random.default_rng(q), free, a.n)
+    qu, k = _ffi.make_query(a.alg, a.n, xs, xg, s, r2_rewire=64 * 64, goal_d2=hostprep.goal_threshold(12),
+                            Cmat=hostprep.rotation_to_world_frame(xs, xg)); keep.append(k)
+    b.set_query(q, qu)
+for rep in range(2):
+    b.rearm(); b.launch(); b.sync()
+ms = b.elapsed_ms()
+r = b.get_result(0, arrays=False)
+cyc = b.debug_cycles(0)
+names = ["A scan+wave-reduce", "barrier 1", "B nearest+LoS+dup", "C choose parent", "D insert", "go2goal"]
+tot = sum(cyc) or 1
+print(f"kernel {ms:.2f} ms, n={a.n}, nodes={r.c.j}, iters/s={a.n/ms*1e3:.0f}, status={r.c.status}")
+for nm, c in zip(names, cyc):
+    print(f"  {nm:22s} {c:14d} cyc  {100*c/tot:5.1f}%  {c/a.n:9.1f} cyc/iter")
+print(f"  total stamped cycles {tot} = {tot/a.n:.0f} cyc/iter ; los_cand={r.c.n_los_cand} near={r.c.sum_near}")
