@@ -1,0 +1,81 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py -- round-robin sharding of independent queries,
+one all-gather of fixed-size result slabs, max-over-ranks timing.  The expansion itself is stood in by the
+CPU oracle here (tests only); on the GPU node the same code runs over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle
+from rrtplanner_amd import hostprep, multi
+from rrtplanner_amd.oggen import perlin_occupancygrid, random_connected_pair
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, n, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    og = perlin_occupancygrid(96, 96, seed=2)
+    og8 = oracle.og_u8(og)
+    free = np.argwhere(og == 0)
+    sg = np.random.default_rng(7)
+    pairs = [random_connected_pair(og, sg) for _ in range(total)]
+    mine = multi.shard_queries(total, world, rank)
+    stride = ((n + 4) + 3) & ~3
+    Q = len(mine)
+    vcost = np.zeros((Q, stride)); nodes = np.zeros((Q, stride), dtype=np.uint32); parent = np.zeros((Q, stride), dtype=np.int32)
+    for slot, g in enumerate(mine):
+        xs, xg = pairs[g]
+        s = hostprep.draw_free_samples(np.random.default_rng(g), free, n)
+        st, r = oracle.plan(og8, n, 1, xs, xg, s, r2_rewire=hostprep.radius_threshold(16), logs=False)
+        live = r.j + (1 if r.found else 0)
+        vcost[slot, :live] = r.vcost[:live]
+        nodes[slot, :live] = r.pts[:live, 0].astype(np.uint32) | (r.pts[:live, 1].astype(np.uint32) << 16)
+        parent[slot, :live] = r.parent[:live]
+    slab = np.concatenate([vcost.view(np.uint8).ravel(), nodes.view(np.uint8).ravel(), parent.view(np.uint8).ravel()])
+    blocks = multi.gather_result_blocks(torch.from_numpy(slab))
+    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "blocks.npy"), blocks.numpy())
+        np.save(os.path.join(out_dir, "tmax.npy"), t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather(tmp_path):
+    import torch.multiprocessing as mp
+
+    world, total, n = 2, 6, 150
+    mp.spawn(_worker, args=(world, _free_port(), total, n, str(tmp_path)), nprocs=world, join=True)
+    blocks = np.load(tmp_path / "blocks.npy")
+    assert np.load(tmp_path / "tmax.npy")[0] == pytest.approx(0.2)
+    stride = ((n + 4) + 3) & ~3
+    Q = total // world
+    assert blocks.shape == (world, Q * stride * 16)
+    og = perlin_occupancygrid(96, 96, seed=2)
+    og8 = oracle.og_u8(og)
+    free = np.argwhere(og == 0)
+    sg = np.random.default_rng(7)
+    pairs = [random_connected_pair(og, sg) for _ in range(total)]
+    for g in range(total):
+        v, nd, pa = multi.unpack_slab(blocks[multi.owner_of(g, world)], Q, stride)
+        slot = multi.local_slot(g, world)
+        xs, xg = pairs[g]
+        s = hostprep.draw_free_samples(np.random.default_rng(g), free, n)
+        st, r = oracle.plan(og8, n, 1, xs, xg, s, r2_rewire=hostprep.radius_threshold(16), logs=False)
+        live = r.j + (1 if r.found else 0)
+        assert np.array_equal(nd[slot, :live] & 0xffff, r.pts[:live, 0]) and np.array_equal(nd[slot, :live] >> 16, r.pts[:live, 1])
+        assert np.array_equal(pa[slot, :live], r.parent[:live]) and np.array_equal(v[slot, :live], r.vcost[:live])

@@ -1,0 +1,121 @@
+"""CPU: host-side logic of the drop-in (RNG stream handling, thresholds, grid generator, statics)."""
+import math
+
+import numpy as np
+import pytest
+
+from rrtplanner_amd import hostprep, multi, oggen
+from rrtplanner_amd import rrt as amd
+
+
+def test_rng_block_draws_equal_scalar_draws_and_state():
+    F = 700001
+    free = np.stack([np.arange(F) % 1000, np.arange(F) // 1000], axis=1)
+    g1, g2 = np.random.default_rng(3), np.random.default_rng(3)
+    a = np.array([free[g1.choice(F)] for _ in range(1237)])
+    b = hostprep.draw_free_samples(g2, free, 1237)
+    assert np.array_equal(a, b) and g1.bit_generator.state == g2.bit_generator.state
+    # unit ball: scalar sequence of the reference (rrt.py:582-586) vs one block
+    u1 = []
+    for _ in range(501):
+        r = g1.uniform(0, 1)
+        th = 2 * np.pi * g1.uniform(0, 1)
+        u1.append([np.sqrt(r) * np.cos(th), np.sqrt(r) * np.sin(th)])
+    u2 = hostprep.draw_unitball(g2, 501)
+    assert np.array_equal(np.array(u1), u2) and g1.bit_generator.state == g2.bit_generator.state
+    # rewind to a prefix: same state as drawing only the prefix
+    g3 = np.random.default_rng(9)
+    s0 = g3.bit_generator.state
+    full = hostprep.draw_free_samples(g3, free, 4000)
+    g3.bit_generator.state = s0
+    part = hostprep.draw_free_samples(g3, free, 1501)
+    g4 = np.random.default_rng(9)
+    [g4.choice(F) for _ in range(1501)]
+    assert np.array_equal(full[:1501], part) and g3.bit_generator.state == g4.bit_generator.state
+
+
+@pytest.mark.parametrize("r", [0, 1, 2, 5, 7.5, 10, 31.999, 32, 64, 64.5, 1e9, float("inf"), float("nan"), -3, np.float32(12.5), np.int64(40)])
+def test_radius_threshold_matches_numpy_comparison(r):
+    R = hostprep.radius_threshold(r)
+    d2 = np.arange(0, 5000, dtype=np.int64)
+    with np.errstate(all="ignore"):
+        want = d2 < r * r
+    assert np.array_equal(d2 < R, want)
+
+
+@pytest.mark.parametrize("rg", [0, -1, 0.5, 1, 1.0000001, 5, 5.0, 12, 12.5, math.sqrt(50), math.nextafter(math.sqrt(50), 0), 2900.0, 1e9, float("nan")])
+def test_goal_threshold_matches_r2norm_comparison(rg):
+    G = hostprep.goal_threshold(rg)
+    for d2 in list(range(0, 400)) + [2499, 2500, 2501, 8410000 - 1, 8410000, 8410001]:
+        assert (math.sqrt(d2) < rg) == (d2 < G), (rg, d2, G)
+
+
+def test_noise_grid_contract_and_determinism():
+    a = oggen.perlin_occupancygrid(120, 90, seed=5)
+    b = oggen.perlin_occupancygrid(120, 90, seed=5)
+    c = oggen.perlin_occupancygrid(120, 90, seed=6)
+    assert a.shape == (120, 90) and a.dtype.kind == "i" and set(np.unique(a)) <= {0, 1}
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    f = oggen.perlin_occupancygrid(40, 30, frames=3, seed=1)
+    assert f.shape == (3, 40, 30)
+    assert 0.5 < (a == 0).mean() < 0.95
+    m = oggen.largest_free_component(a)
+    xs, xg = oggen.random_connected_pair(a, np.random.default_rng(0))
+    assert m[xs[0], xs[1]] and m[xg[0], xg[1]]
+
+
+def test_class_surface_matches_reference():
+    og = np.zeros((30, 20), dtype=int)
+    og[10:12, 5:15] = 1
+    p = amd.RRT(og, 17)
+    assert p.n == 17 and p.pbar is True and p.not_a_point == [np.inf, np.inf] and p.not_a_dist == np.inf
+    assert np.array_equal(p.free, np.argwhere(og == 0)) and p.og is og
+    with pytest.raises(NotImplementedError):
+        p.plan(np.array([0, 0]), np.array([1, 1]))
+    p.set_n(5)
+    assert p.n == 5
+    og2 = np.zeros((8, 8), dtype=int)
+    p.set_og(og2)
+    assert p.og is og2 and p.free.shape[0] == 64 and p._grid_dirty
+    s = p.sample_all_free()
+    assert s.shape == (2,) and og2[s[0], s[1]] == 0
+    assert amd.RRTStar(og, 5, 3.5).r_rewire == 3.5
+    q = amd.RRTStarInformed(og, 5, 3, 2)
+    assert q.r_goal == 2 and q.ellipses == {}
+    # default cost closure (rrt.py:72-78)
+    vc = np.array([0.0, 2.5])
+    pts = np.array([[0, 0], [3, 4]])
+    assert q.cost(vc, pts, 1, np.array([0, 0])) == 7.5
+    assert amd.r2norm(np.array([3, 4])) == 5.0 and isinstance(amd.r2norm(np.array([3, 4])), float)
+    rp = amd.random_point_og(og, np.random.default_rng(1))
+    assert og[rp[0], rp[1]] == 0
+    # same seed -> same stream as the reference's self.rand_gen (rrt.py:85)
+    assert amd.RRTStandard(og, 5, seed=4).rand_gen.integers(0, 1 << 30) == np.random.default_rng(4).integers(0, 1 << 30)
+
+
+def test_plan_argument_validation_without_device():
+    og = np.zeros((10, 10), dtype=int)
+    p = amd.RRTStandard(og, 5, pbar=False)
+    with pytest.raises(ValueError):
+        p._run(0, np.array([0, 0]), np.array([10, 3]))
+    with pytest.raises(ValueError):
+        p._run(0, np.array([0.5, 0]), np.array([1, 3]))
+    with pytest.raises(NotImplementedError):
+        amd.RRTStandard(og, 5, costfn=lambda *a: 0.0, pbar=False)._run(0, np.array([0, 0]), np.array([1, 1]))
+
+
+def test_sharding_helpers():
+    for total, ws in [(512, 8), (7, 3), (1, 4), (64, 1)]:
+        seen = []
+        for r in range(ws):
+            mine = multi.shard_queries(total, ws, r)
+            assert all(multi.owner_of(q, ws) == r for q in mine)
+            assert [multi.local_slot(q, ws) for q in mine] == list(range(len(mine)))
+            seen += mine
+        assert sorted(seen) == list(range(total))
+    with pytest.raises(ValueError):
+        multi.shard_queries(4, 2, 2)
+    Q, stride = 3, 8
+    slab = np.zeros(Q * stride * 16, dtype=np.uint8)
+    v, nd, pa = multi.unpack_slab(slab, Q, stride)
+    assert v.shape == (Q, stride) and nd.dtype == np.uint32 and pa.dtype == np.int32
