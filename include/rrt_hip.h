@@ -34,7 +34,8 @@ extern "C" {
 #define RRT_ALG_STAR 1     /* RRTStar.plan         rrt.py:466 */
 #define RRT_ALG_INFORMED 2 /* RRTStarInformed.plan rrt.py:653 */
 
-#define RRT_FLAG_LOGS 1u /* keep per-iteration logs (nearest, accept, ellipse cost, j) on the device */
+#define RRT_FLAG_LOGS 1u   /* keep per-iteration logs (nearest, accept, ellipse cost, j) on the device */
+#define RRT_FLAG_SERIAL 2u /* use the one-sample-per-iteration kernel instead of the 16-sample block kernel */
 
 typedef struct rrt_ctx rrt_ctx;
 typedef struct rrt_batch rrt_batch;
@@ -116,6 +117,8 @@ int rrt_prim_nearest_within(rrt_ctx *ctx, const int32_t *pts, int32_t j, const i
                             int64_t *out_within_idxsum);
 /* sqrt of the integers lo .. lo+count-1 as the kernels compute it (r2norm, rrt.py:24) */
 int rrt_prim_sqrt_u32(rrt_ctx *ctx, uint32_t lo, uint32_t count, double *out);
+/* the block kernel's short sqrt, valid for radicands below 2^24 */
+int rrt_prim_sqrt_u24(rrt_ctx *ctx, uint32_t lo, uint32_t count, double *out);
 /* sqrt of arbitrary doubles as the kernels compute it (ellipse minor axis, rrt.py:622) */
 int rrt_prim_sqrt_f64(rrt_ctx *ctx, const double *in, uint32_t count, double *out);
 

@@ -23,6 +23,7 @@ RRT_E_COMM = -6
 
 ALG_STANDARD, ALG_STAR, ALG_INFORMED = 0, 1, 2
 FLAG_LOGS = 1
+FLAG_SERIAL = 2
 
 # every symbol include/rrt_hip.h declares (tests/test_capi_symbols.py checks the library exports them)
 SYMBOLS = (
@@ -31,7 +32,7 @@ SYMBOLS = (
     "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
     "rrt_plan", "rrt_plan_resume", "rrt_plan_batch",
-    "rrt_prim_collisionfree", "rrt_prim_nearest_within", "rrt_prim_sqrt_u32", "rrt_prim_sqrt_f64",
+    "rrt_prim_collisionfree", "rrt_prim_nearest_within", "rrt_prim_sqrt_u32", "rrt_prim_sqrt_u24", "rrt_prim_sqrt_f64",
 )
 
 
@@ -98,6 +99,7 @@ def lib():
             "rrt_prim_collisionfree": ([vp, vp, i32, vp, vp], C.c_int),
             "rrt_prim_nearest_within": ([vp, vp, i32, vp, i32, i64, vp, vp, vp], C.c_int),
             "rrt_prim_sqrt_u32": ([vp, u32, u32, vp], C.c_int),
+            "rrt_prim_sqrt_u24": ([vp, u32, u32, vp], C.c_int),
             "rrt_prim_sqrt_f64": ([vp, vp, u32, vp], C.c_int),
         }
         for name, (argtypes, restype) in sig.items():
@@ -190,9 +192,10 @@ class Context:
         self.shape = g.shape
 
     # ---- one-shot ----
-    def plan(self, query, n, logs=False):
+    def plan(self, query, n, logs=False, serial=False):
         res = ResultArrays(n, logs)
-        rc = lib().rrt_plan(self._h, C.byref(query), FLAG_LOGS if logs else 0, C.byref(res.c))
+        flags = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0)
+        rc = lib().rrt_plan(self._h, C.byref(query), flags, C.byref(res.c))
         _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
         return rc, res
 
@@ -227,6 +230,11 @@ class Context:
         _check(self._h, lib().rrt_prim_sqrt_u32(self._h, int(lo), int(count), out.ctypes.data))
         return out
 
+    def prim_sqrt_u24(self, lo, count):
+        out = np.zeros(count, dtype=np.float64)
+        _check(self._h, lib().rrt_prim_sqrt_u24(self._h, int(lo), int(count), out.ctypes.data))
+        return out
+
     def prim_sqrt_f64(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         out = np.zeros_like(x)
@@ -237,10 +245,11 @@ class Context:
 class Batch:
     """Q independent queries resident on the device (rrt_batch_*)."""
 
-    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False):
+    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False):
         self.ctx, self.Q, self.n_cap, self.logs = ctx, int(Q), int(n_cap), logs
         self._h = C.c_void_p()
-        _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, FLAG_LOGS if logs else 0, C.byref(self._h)))
+        flags = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0)
+        _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, flags, C.byref(self._h)))
         self._n = [0] * self.Q
 
     def close(self):

@@ -12,6 +12,7 @@
 
 #include "rrt_hip.h"
 #include "rrt_kernels.h"
+#include "rrt_block.h"
 #include "rrt_prims.h"
 
 using namespace rrtdev;
@@ -34,6 +35,9 @@ struct rrt_batch {
     int32_t Q = 0, n_cap = 0, node_stride = 0, bitmap_words = 0, lds_chunks = 1, spill_stride = 0;
     int32_t gridW = 0, gridH = 0;
     uint32_t flags = 0;
+    bool use_block = false;     // block-parallel kernel (rrt_block.h) instead of the one-sample-per-iteration kernel
+    int32_t blk_lds_chunks = 1; // node chunks cached in LDS by the block kernel
+    size_t blk_lds_bytes = 0;
     QDesc *d_desc = nullptr;
     std::vector<QDesc> h_desc;
     uint32_t *d_samples = nullptr, *d_nodes = nullptr, *d_bitmap = nullptr;
@@ -138,10 +142,21 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->flags = flags;
     b->gridW = ctx->W;
     b->gridH = ctx->H;
-    b->node_stride = ((n_cap + 4) + 3) & ~3;
+    // whole 4096-node steps: the block kernel scans complete steps, unfilled slots hold a copy of node 0
+    b->node_stride = ((n_cap + 1 + CHUNK - 1) / CHUNK) * CHUNK;
     b->bitmap_words = (int32_t)(((size_t)ctx->W * ctx->H + 31) / 32);
     int chunks = (n_cap + 1 + CHUNK - 1) / CHUNK;
     b->spill_stride = chunks * CHUNK;  // 256 overflow entries per wave and node chunk; also go2goal's cost array
+    {   // block kernel LDS: [node cache | masks 2 KiB per 4096-node step | quad lists 32 KiB]
+        const size_t budget = (size_t)ctx->max_lds - 6144;  // static LDS of the kernel
+        const size_t fixed = (size_t)NWAVE * chunks * BS * sizeof(unsigned long long) + (size_t)NWAVE * QCAP * sizeof(uint32_t);
+        b->use_block = !(flags & RRT_FLAG_SERIAL) && fixed + (size_t)CHUNK * sizeof(uint32_t) <= budget;
+        if (b->use_block) {
+            int nc = (int)((budget - fixed) / ((size_t)CHUNK * sizeof(uint32_t)));
+            b->blk_lds_chunks = nc > chunks ? chunks : nc;
+            b->blk_lds_bytes = fixed + (size_t)b->blk_lds_chunks * CHUNK * sizeof(uint32_t);
+        }
+    }
     b->lds_chunks = chunks < 1 ? 1 : (chunks > MAX_LDS_CHUNKS ? MAX_LDS_CHUNKS : chunks);
     b->h_desc.assign((size_t)Q, QDesc{});
     for (auto &d : b->h_desc) d.status = ST_IDLE;
@@ -301,12 +316,24 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     if (b->gridW != ctx->W || b->gridH != ctx->H) return fail(ctx, RRT_E_ARG, "rrt_batch_launch: grid changed shape");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     BatchView v = make_view(b);
+    dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
+    if (b->use_block) {
+        v.lds_chunks = b->blk_lds_chunks;
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rrt_expand_block_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
+        hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+        HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
+        hipLaunchKernelGGL(rrt_expand_block_kernel, dim3((unsigned)b->Q), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        b->timed = true;
+        return RRT_OK;
+    }
     const size_t lds = expand_lds_bytes(b->lds_chunks);
     const size_t lds_static = (size_t)NWAVE * WCAP * sizeof(uint2) + 2 * NWAVE * (sizeof(Slot) + sizeof(BSlot));
     if ((int)(lds + lds_static) > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds + lds_static, ctx->max_lds);
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rrt_expand_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
     hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
     hipLaunchKernelGGL(rrt_expand_kernel, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
@@ -547,6 +574,20 @@ extern "C" int rrt_prim_sqrt_u32(rrt_ctx *ctx, uint32_t lo, uint32_t count, doub
     double *d = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&d, (size_t)count * sizeof(double)));
     hipLaunchKernelGGL(prim_sqrt_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, lo, count, d);
+    HIPCHK(ctx, hipMemcpyAsync(out, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(d));
+    return RRT_OK;
+}
+
+extern "C" int rrt_prim_sqrt_u24(rrt_ctx *ctx, uint32_t lo, uint32_t count, double *out) {
+    if (!ctx || !out) return fail(ctx, RRT_E_ARG, "rrt_prim_sqrt_u24: NULL");
+    if ((unsigned long long)lo + count > (1ull << 24)) return fail(ctx, RRT_E_ARG, "rrt_prim_sqrt_u24: radicand >= 2^24");
+    if (count == 0) return RRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double *d = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d, (size_t)count * sizeof(double)));
+    hipLaunchKernelGGL(prim_sqrt_u24_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, lo, count, d);
     HIPCHK(ctx, hipMemcpyAsync(out, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipFree(d));

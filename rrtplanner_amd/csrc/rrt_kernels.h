@@ -631,7 +631,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
     }
 }
 
-// Arms query state in HBM: clears the `sampled` bitmap, writes node 0 (rrt.py:411-413).
+// Arms query state in HBM: clears the `sampled` bitmap, writes node 0 (rrt.py:411-413) and fills the unfilled
+// node slots with a copy of node 0 (the block kernel scans whole 4096-node steps; such a slot can never be the
+// nearest node -- equal distance, higher index -- and is dropped from near sets by its index).
 __global__ void rrt_init_kernel(BatchView bv) {
     const int q = (int)blockIdx.y;
     const QDesc *D = bv.desc + q;
@@ -639,8 +641,10 @@ __global__ void rrt_init_kernel(BatchView bv) {
     uint32_t *bitmap = bv.bitmap + (size_t)q * bv.bitmap_words;
     for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < bv.bitmap_words; k += (int)(gridDim.x * blockDim.x))
         bitmap[k] = 0;
+    const uint32_t n0 = pack_xy(D->xs[0], D->xs[1]);
+    for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < bv.node_stride; k += (int)(gridDim.x * blockDim.x))
+        bv.nodes[(size_t)q * bv.node_stride + k] = n0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        bv.nodes[(size_t)q * bv.node_stride] = pack_xy(D->xs[0], D->xs[1]);
         bv.vcost[(size_t)q * bv.node_stride] = 0.0;
         bv.parent[(size_t)q * bv.node_stride] = -1;
     }

@@ -2,6 +2,7 @@
 // They call the same device functions as rrt_expand_kernel.
 #pragma once
 
+#include "rrt_block.h"
 #include "rrt_kernels.h"
 
 namespace rrtdev {
@@ -84,6 +85,12 @@ __global__ __launch_bounds__(TPB) void prim_nn_kernel(const uint32_t *nodes, int
 __global__ void prim_sqrt_kernel(uint32_t lo, uint32_t count, double *out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < count) out[k] = sqrt_u32(lo + k);
+}
+
+// the block kernel's short sqrt for radicands below 2^24
+__global__ void prim_sqrt_u24_kernel(uint32_t lo, uint32_t count, double *out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) out[k] = sqrt_u24(lo + k);
 }
 
 // sqrt of arbitrary doubles (the ellipse minor axis, rrt.py:622).

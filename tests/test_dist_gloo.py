@@ -33,7 +33,7 @@ def _worker(rank, world, port, total, n, out_dir):
     sg = np.random.default_rng(7)
     pairs = [random_connected_pair(og, sg) for _ in range(total)]
     mine = multi.shard_queries(total, world, rank)
-    stride = ((n + 4) + 3) & ~3
+    stride = ((n + 1 + 4095) // 4096) * 4096
     Q = len(mine)
     vcost = np.zeros((Q, stride)); nodes = np.zeros((Q, stride), dtype=np.uint32); parent = np.zeros((Q, stride), dtype=np.int32)
     for slot, g in enumerate(mine):
@@ -62,7 +62,7 @@ def test_two_rank_shard_and_gather(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), total, n, str(tmp_path)), nprocs=world, join=True)
     blocks = np.load(tmp_path / "blocks.npy")
     assert np.load(tmp_path / "tmax.npy")[0] == pytest.approx(0.2)
-    stride = ((n + 4) + 3) & ~3
+    stride = ((n + 1 + 4095) // 4096) * 4096
     Q = total // world
     assert blocks.shape == (world, Q * stride * 16)
     og = perlin_occupancygrid(96, 96, seed=2)

@@ -33,6 +33,12 @@ def test_sqrt_of_every_squared_distance_is_correctly_rounded(gpu_ctx):
     assert np.array_equal(got, np.sqrt(np.arange((1 << 24) - 4096, 1 << 24, dtype=np.float64)))
 
 
+def test_block_kernel_short_sqrt_is_exact_for_every_radicand(gpu_ctx):
+    step = 1 << 22
+    for lo in range(0, 1 << 24, step):
+        assert np.array_equal(gpu_ctx.prim_sqrt_u24(lo, step), np.sqrt(np.arange(lo, lo + step, dtype=np.float64)))
+
+
 def test_sqrt_f64_random(gpu_ctx):
     rng = np.random.default_rng(0)
     x = np.concatenate([rng.uniform(0, 1e7, 2_000_000), rng.uniform(0, 1, 500_000) ** 8 * 1e12,
@@ -137,7 +143,7 @@ def test_replan_chain_rng_continues_and_set_og(tag):
 
 
 # ------------------------------------------------------------------------------- device vs oracle, larger
-def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None):
+def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None, serial=False):
     rng = np.random.default_rng(seed)
     free = np.argwhere(og8 == 0)
     samples = hostprep.draw_free_samples(rng, free, n)
@@ -145,7 +151,7 @@ def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None
     gd2 = hostprep.goal_threshold(r_goal) if r_goal is not None else 0
     Cm = hostprep.rotation_to_world_frame(np.asarray(xs, dtype=np.int64), np.asarray(xg, dtype=np.int64)) if alg == 2 else None
     q, keep = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2, goal_d2=gd2, Cmat=Cm)
-    rc, res = ctx.plan(q, n, logs=True)
+    rc, res = ctx.plan(q, n, logs=True, serial=serial)
     st, ro = oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=r2, r_goal=r_goal or 0.0, Cmat=Cm)
     ub = None
     if rc == _ffi.RRT_NEED_UNITBALL:
@@ -167,31 +173,49 @@ def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None
     return res, ro
 
 
+@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
 @pytest.mark.parametrize("alg,rr,rg", [(0, None, None), (1, 64, None), (2, 64, 12)])
-def test_device_vs_oracle_1024_n6000(gpu_ctx, alg, rr, rg):
+def test_device_vs_oracle_1024_n6000(gpu_ctx, alg, rr, rg, serial):
     og = perlin_occupancygrid(1024, 1024, seed=1)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)
     xs, xg = random_connected_pair(og, np.random.default_rng(7))
-    _oracle_vs_device(gpu_ctx, og8, alg, 6000, 0, xs, xg, rr, rg)
+    _oracle_vs_device(gpu_ctx, og8, alg, 6000, 0, xs, xg, rr, rg, serial=serial)
 
 
-def test_device_vs_oracle_beyond_lds_capacity(gpu_ctx):
-    """n = 40000 > 32768 LDS-resident nodes: the scan crosses from LDS chunks into HBM chunks."""
+@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
+def test_device_vs_oracle_beyond_lds_capacity(gpu_ctx, serial):
+    """n = 40000 exceeds the LDS-resident node chunks: the scan crosses from LDS chunks into HBM chunks."""
     og = perlin_occupancygrid(1024, 1024, seed=1)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)
     xs, xg = random_connected_pair(og, np.random.default_rng(7))
-    _oracle_vs_device(gpu_ctx, og8, 1, 40000, 0, xs, xg, 64, None)
+    _oracle_vs_device(gpu_ctx, og8, 1, 40000, 0, xs, xg, 64, None, serial=serial)
 
 
-def test_device_vs_oracle_near_set_spills(gpu_ctx):
-    """r_rewire far beyond the grid: the near set is the whole tree and overflows the LDS list."""
+@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
+def test_device_vs_oracle_near_set_spills(gpu_ctx, serial):
+    """r_rewire far beyond the grid: the near set is the whole tree and overflows the LDS lists."""
     og = perlin_occupancygrid(256, 256, seed=4)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)
     xs, xg = random_connected_pair(og, np.random.default_rng(1))
-    _oracle_vs_device(gpu_ctx, og8, 1, 5000, 3, xs, xg, 1e6, None)
+    _oracle_vs_device(gpu_ctx, og8, 1, 5000, 3, xs, xg, 1e6, None, serial=serial)
+
+
+@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
+@pytest.mark.parametrize("alg,rr,rg,grid,n,seed", [
+    (1, 9, None, 64, 3000, 1),      # tiny grid: most samples are duplicates or interact inside a block
+    (2, 30, 8, 96, 2500, 2),        # informed on a small grid: many ellipse changes cut blocks
+    (1, 200, None, 300, 4000, 3),   # radius comparable to the grid
+    (0, None, None, 40, 1500, 4),   # n close to the number of free cells
+])
+def test_device_vs_oracle_dense_interactions(gpu_ctx, alg, rr, rg, grid, n, seed, serial):
+    og = perlin_occupancygrid(grid, grid, seed=seed)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    xs, xg = random_connected_pair(og, np.random.default_rng(seed))
+    _oracle_vs_device(gpu_ctx, og8, alg, n, seed, xs, xg, rr, rg, serial=serial)
 
 
 def test_batch_of_queries_matches_single_queries(gpu_ctx):
