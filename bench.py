@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--queries", type=int, default=None, help="queries per GPU (default: the config's)")
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the informational batched leg (configs[3] share of one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,16 +196,68 @@ def main():
                        "iters_per_s": iters_total * args.steps / dt, "unfinished_queries": nbad},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "rrt_expand_kernel", "kernel_ms": kern_avg_ms, "algorithmic_bytes_per_launch": int(bytes_local)},
+                         "kernel": "rrt_expand_block_kernel", "kernel_ms": kern_avg_ms, "algorithmic_bytes_per_launch": int(bytes_local)},
         }
+        tr = measured_traffic(args.config, Q, n)
+        if tr is not None:
+            out["roofline"]["traffic"] = tr
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(og8, cfg, pairs[0], free, states[0], ub_cache.get(0))
+        if world == 1 and args.config == 2 and not args.no_batched:
+            out["batched"] = batched_leg(ctx, og, free, _ffi, hostprep)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     batch.close()
     ctx.close()
+
+
+def measured_traffic(config, Q, n):
+    """HBM bytes per launch of rrt_expand_block_kernel from the committed rocprofv3 PMC passes (profiles/), when they
+    were taken on this exact workload; None otherwise (the counters cannot be read from inside the bench)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        for e in t["entries"]:
+            if e["config"] == config and e["queries_per_gpu"] == Q and e["n"] == n:
+                return e["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def batched_leg(ctx, og, free, _ffi, hostprep):
+    """Informational: one GPU's share of BASELINE.json configs[3] (64 independent RRT* queries, n = 20000), one query per
+    workgroup.  Not the headline value."""
+    from rrtplanner_amd.oggen import random_connected_pair
+
+    cfg = CONFIGS[4]
+    Q, n = cfg["queries"], cfg["n"]
+    b = _ffi.Batch(ctx, Q, n)
+    sg = np.random.default_rng(7)
+    keep = []
+    for q in range(Q):
+        xs, xg = random_connected_pair(og, sg)
+        s = hostprep.draw_free_samples(np.random.default_rng(q), free, n)
+        qu, k = _ffi.make_query(cfg["alg"], n, xs, xg, s, r2_rewire=hostprep.radius_threshold(cfg["r_rewire"]))
+        keep.append(k)
+        b.set_query(q, qu)
+    b.launch(); b.sync()
+    steps, t0, kms = 3, time.perf_counter(), 0.0
+    for _ in range(steps):
+        b.rearm(); b.launch(); b.sync()
+        kms += b.elapsed_ms()
+    dt = time.perf_counter() - t0
+    res = [b.get_result(q, arrays=False) for q in range(Q)]
+    nodes = sum(r.c.j - 1 for r in res)
+    by = sum(algorithmic_bytes(r.c) for r in res)
+    b.close()
+    ach = by / (kms / steps * 1e-3) / 1e9
+    return {"workload": "BASELINE.json configs[3] share of one GPU: " + cfg["name"], "value": nodes * steps / dt, "unit": "nodes/s",
+            "ms_per_step": dt / steps * 1e3, "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                          "frac": ach / HBM_PEAK_GBS, "kernel_ms": kms / steps}}
 
 
 def cpu_baseline(og8, cfg, pair, free, state0, ub):

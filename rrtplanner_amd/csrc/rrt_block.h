@@ -7,20 +7,23 @@
 //
 //   A  scan (all 16 waves): every lane loads 4 nodes (16 bytes) once and evaluates them against the
 //      16 samples held in scalar registers: coordinates pre-scaled by 16 make
-//      v_dot2_i32_i16(d, d, tag) = 256*d2 + tag the packed nearest-neighbour key in ONE instruction.
-//      For RRT* the wave-wide "some node of this lane's quad is within r_rewire" ballots go to LDS as
-//      64-bit masks (one per sample, wave and 4096-node step).          [near :150-155, within :176-181]
+//      v_dot2_i32_i16(d, d, tag) = 256*d2 + tag the packed nearest-neighbour key in ONE instruction
+//      (brute force over the whole live tree, near :150-155).
 //      -- barrier --
 //   B  owner phase: wave k owns sample k.  It folds the 16 per-wave minima (lowest index on ties),
-//      tests the line of sight snapshot-nearest -> sample, reads the `sampled` bit, decodes its masks
-//      into the snapshot near set, prices it (vcost + sqrt(d2)) and finds the first entry in (cost, index)
-//      order with cost < cost-via-nearest and a free line of sight          [rrt.py:424-425, :511-521]
+//      tests the line of sight snapshot-nearest -> sample and reads the `sampled` bit (rrt.py:424-425).
+//      RRT*: the radius-ball near set (within :176-181) comes from a uniform cell grid over the map:
+//      every tree node also lives as a 16-byte record {xy, index, vcost} in the array of its cell, so
+//      the owner streams the records of the cells the ball touches (coalesced 16-byte loads, no
+//      gathers), prices them (vcost + sqrt(d2)) and finds the first entry in (cost, index) order with
+//      cost < cost-via-nearest and a free line of sight (choose parent :511-521).  vcost never changes
+//      after the insert (the rewire predicate :536 is never true), so the copy in the record stays valid.
 //      -- barrier --
-//   C  commit (wave 0), in sample order: if no earlier sample of the block that was inserted is
-//      nearer than the snapshot nearest, within r_rewire, or the same cell, the owner's result stands;
-//      otherwise the sample is re-resolved against snapshot + inserted block nodes.  Inserts the node
-//      (rrt.py:524-529; the rewire scan :531-546 never fires with the default cost).  An Informed block is
-//      cut where the ellipse changes (rrt.py:698-700, :744-745).
+//   C  commit (wave 0): samples whose result cannot be changed by an earlier sample of the same block
+//      (none inserted that is nearer than the snapshot nearest, within r_rewire, or on the same cell)
+//      commit together, lane-parallel; a sample that can is re-resolved against snapshot + inserted
+//      block nodes on its own, in order.  An Informed block is cut where the ellipse changes
+//      (rrt.py:698-700, :744-745).
 //      -- barrier --
 #pragma once
 
@@ -28,11 +31,8 @@
 
 namespace rrtdev {
 
-constexpr int BS = 16;      // samples per block == waves per workgroup
-#ifndef RRT_QCAP
-#define RRT_QCAP 512
-#endif
-constexpr int QCAP = RRT_QCAP;  // flagged node quads an owner decodes per round (LDS, 4*QCAP bytes per owner)
+constexpr int BS = 16;  // samples per block == waves per workgroup
+constexpr int CG = 2;   // cells whose records an owner streams concurrently
 
 // exact sqrt of an integer below 2^24 (0 included): rsq seed + coupled Goldschmidt / Newton steps in
 // f64.  tests/test_gpu_parity.py checks every input against the host's correctly rounded sqrt.
@@ -50,7 +50,8 @@ __device__ __forceinline__ double sqrt_u24(uint32_t d2) {
     return d2 == 0 ? 0.0 : g;
 }
 
-// key = 256*d2 + tag of one node against one sample (both pre-scaled by 16): v_pk_sub_i16 + v_dot2_i32_i16
+// key = 256*d2 + tag of one node against one sample (both pre-scaled by 16): v_pk_sub_i16 + v_dot2_i32_i16.
+// Inline asm: hipcc pads no hazards around it; both instructions only read SALU-written scalars and plain VGPRs.
 __device__ __forceinline__ uint32_t key16(uint32_t node_s, uint32_t q_s, uint32_t tag) {
     uint32_t d, r;
     asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(node_s), "s"(q_s));
@@ -60,56 +61,44 @@ __device__ __forceinline__ uint32_t key16(uint32_t node_s, uint32_t q_s, uint32_
 
 // Owner's publication for one sample (64 bytes).
 struct BRec {
-    uint32_t d2s, vs;    // snapshot nearest
-    uint32_t los_s;      // line of sight vs -> sample: bit 31 free, low bits cells read
-    uint32_t flags;      // bit 0: cell already in `sampled` at the snapshot
-    double Vs;           // vcost[vs]
-    double pc;           // best passing snapshot near-set entry with cost < cost-via-vs (or inf)
-    uint32_t pi;         //   its index (NONE)
-    uint32_t pstat;      // owner's candidate line-of-sight tests: count << 20 | cells
-    uint32_t nnmask;     // earlier samples of the block strictly nearer than the snapshot nearest
-    uint32_t rmask;      // earlier samples within r_rewire
-    uint32_t dupmask;    // earlier samples on the same cell
-    uint32_t nnear;      // |within| over the snapshot
-    uint32_t pad[2];
+    uint32_t d2s, vs;   // snapshot nearest
+    uint32_t los_s;     // line of sight vs -> sample: bit 31 free, low bits cells read
+    uint32_t flags;     // bit 0: cell already in `sampled` at the snapshot
+    double Vs;          // vcost[vs]
+    double cbest;       // cost of the sample through its snapshot-resolved parent
+    uint32_t vbest;     // snapshot-resolved parent (vs, or the best passing near-set entry)
+    uint32_t pstat;     // owner's candidate line-of-sight tests: count << 20 | cells
+    uint32_t nnmask;    // earlier samples of the block strictly nearer than the snapshot nearest
+    uint32_t rmask;     // earlier samples within r_rewire
+    uint32_t dupmask;   // earlier samples on the same cell
+    uint32_t nnear;     // |within| over the snapshot
+    double pc;          // cost of the best passing near-set entry (inf: none, parent is vs)
 };
 static_assert(sizeof(BRec) == 64, "BRec must be 64 bytes");
 
 // Block state that wave 0 hands to the other waves after the commit.
 struct BlkState {
-    int32_t i, j, nsoln, vbest_soln, i_switch, status;
+    int32_t i, j, nsoln, vbest_soln, pad0, pad1;
     double cmin_soln, c_ell;
 };
 
-template <bool STAR>
-__device__ __forceinline__ void block_scan_step(u32x4 quad, const uint32_t (&xs16)[BS], uint32_t (&best)[BS], uint32_t tag0,
-                                                uint32_t r2key, RRT_LDS unsigned long long *mask_row, int lane) {
+__device__ __forceinline__ void block_scan_step(u32x4 quad, const uint32_t (&xs16)[BS], uint32_t (&best)[BS], uint32_t tag0) {
     const uint32_t n0 = quad.x << 4, n1 = quad.y << 4, n2 = quad.z << 4, n3 = quad.w << 4;
-    uint32_t mlo = 0, mhi = 0;
 #pragma unroll
     for (int k = 0; k < BS; ++k) {
         const uint32_t k0 = key16(n0, xs16[k], tag0), k1 = key16(n1, xs16[k], tag0 + 1), k2 = key16(n2, xs16[k], tag0 + 2),
                        k3 = key16(n3, xs16[k], tag0 + 3);
-        const uint32_t m4 = min(min(k0, k1), min(k2, k3));
-        best[k] = min(best[k], m4);
-        if (STAR) {
-            // ballot(m4 < r2key) into lane k of (mlo, mhi).  One asm statement: on gfx950 a VALU-written SGPR needs
-            // two wait states before another VALU reads it, and hipcc pads nothing around inline asm.
-            asm("v_cmp_gt_u32_e32 vcc, %2, %3\n\ts_nop 1\n\tv_writelane_b32 %0, vcc_lo, %4\n\tv_writelane_b32 %1, vcc_hi, %4"
-                : "+v"(mlo), "+v"(mhi)
-                : "s"(r2key), "v"(m4), "n"(k)
-                : "vcc");
-        }
+        best[k] = min(min(best[k], k0), min(min(k1, k2), k3));
     }
-    if (STAR && lane < BS) mask_row[lane] = ((unsigned long long)mhi << 32) | mlo;
 }
 
 __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | masks | quad lists]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
     __shared__ __attribute__((aligned(16))) u32x2 nnx[BS * NWAVE];        // per sample, per wave: {d2, idx}
     __shared__ __attribute__((aligned(16))) BRec brec[BS];
     __shared__ __attribute__((aligned(16))) BSlot bslots[2 * NWAVE];
     __shared__ __attribute__((aligned(16))) BlkState blk;
+    __shared__ __attribute__((aligned(16))) unsigned long long statred[BS * 5];
     __shared__ uint32_t xq_lds[BS];
     __shared__ double newcost[BS];
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -133,19 +122,24 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     const int W = bv.W, H = bv.H;
     const int lds_chunks = bv.lds_chunks;
     const int lds_nodes = lds_chunks * CHUNK;
-    const int nsteps_cap = (bv.n_cap + CHUNK) / CHUNK;  // 4096-node steps the masks are sized for
     const uint32_t r2 = D->r2_rewire, goal_d2 = D->goal_d2;
-    const uint32_t r2key = (r2 >= (1u << 23)) ? NONE : (r2 << 8);
     const uint32_t xs = pack_xy(D->xs[0], D->xs[1]), xg = pack_xy(D->xg[0], D->xg[1]);
     const int ub_offset = D->ub_offset, ub_count = D->ub_count;
+    // cell grid of the near-set records
+    const int cshift = D->cell_shift, ncy = D->ncy, ccap = D->cell_cap, ncells = D->ncx * D->ncy;
+    u32x4 *cellrec = reinterpret_cast<u32x4 *>(bv.cellrec) + (size_t)q * (size_t)bv.rec_stride;
+    uint32_t *cellcnt_g = bv.cellcnt + (size_t)q * (size_t)MAX_CELLS;
+    int rad = 0;  // largest |dx| with dx*dx < r2
+    if (r2 > 0) {
+        rad = (r2 >= (1u << 23)) ? 4096 : (int)sqrtf((float)(r2 - 1));
+        while (rad > 0 && (uint32_t)(rad * rad) > r2 - 1) --rad;
+        while ((uint32_t)((rad + 1) * (rad + 1)) <= r2 - 1) ++rad;
+    }
 
     // ---- LDS carve ----
     RRT_LDS uint32_t *nodes_lds = (RRT_LDS uint32_t *)smem;
     const RRT_LDS u32x4 *nodes_lds4 = (const RRT_LDS u32x4 *)smem;
-    size_t off = (size_t)lds_chunks * CHUNK * sizeof(uint32_t);
-    RRT_LDS unsigned long long *masks = (RRT_LDS unsigned long long *)(smem + off);  // [wave][step][sample]
-    off += (size_t)NWAVE * nsteps_cap * BS * sizeof(unsigned long long);
-    RRT_LDS uint32_t *qlist = (RRT_LDS uint32_t *)(smem + off) + wave * QCAP;  // this wave's decoded quads
+    RRT_LDS uint32_t *cellcnt = (RRT_LDS uint32_t *)(smem + (size_t)lds_chunks * CHUNK * sizeof(uint32_t));
 
     // ---- state ----
     int i = D->i, j = D->j;
@@ -153,9 +147,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     double cmin_soln = D->cmin_soln;
     int i_switch = D->i_switch;
     int status = ST_RUNNING;
-    // statistics live in wave 0
-    unsigned long long sum_j = D->sum_j, sum_cells_nn = D->sum_cells_nn, sum_near = D->sum_near,
-                       sum_cells_cand = D->sum_cells_cand, n_los_cand = D->n_los_cand;
+    // statistics: per-lane accumulators of wave 0, folded once at the end
+    unsigned long long a_sum_j = 0, a_cells_nn = 0, a_near = 0, a_cells_cand = 0, a_los_cand = 0;
 #ifdef RRT_STAMPS
     unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
@@ -168,120 +161,181 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     if (informed && nsoln > 0) c_ell = cmin_soln + sqrt_u32(dist2(xg, nodes_g[vbest_soln]));
 
     // ---- prologue: node cache = live nodes, unfilled slots = copy of node 0 (never nearest: equal distance,
-    //      higher index; dropped from near sets by the index test) ----
+    //      higher index); cell fill counts from HBM ----
     {
         const uint32_t n0 = nodes_g[0];
         for (int k = t; k < lds_nodes; k += TPB) nodes_lds[k] = (k < j) ? nodes_g[k] : n0;
+        for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
     }
     __syncthreads();
 
     auto node_xy = [&](uint32_t v) -> uint32_t { return ((int)v < lds_nodes) ? nodes_lds[v] : nodes_g[v]; };
+    auto cell_of = [&](uint32_t X) -> int { return (ux(X) >> cshift) * ncy + (uy(X) >> cshift); };
 
-    // Snapshot near set of sample X (owner's masks `k`): first entry in (cost, index) order with cost < bound and a
-    // free line of sight.  Executed by one whole wave.  Returns (pc, pi) or (inf, NONE); adds to the counters.
-    auto snapshot_parent = [&](int k, uint32_t X, int j0, int nsteps, double bound, double &pc, uint32_t &pi, uint32_t &nnear,
+    // Snapshot near set of sample X: first entry in (cost, index) order with cost < bound and a free line of
+    // sight.  One whole wave.  Returns (pc, pi) or (inf, NONE); nnear = |within| over nodes [0, j0).
+    // Pass 1 streams the cell records once and keeps the two cheapest entries; only when both are blocked does
+    // pass 2 stream again and park every remaining entry below the bound in this wave's HBM list, which is then
+    // consumed in key order without touching the cells again.
+    u32x4 *clist = reinterpret_cast<u32x4 *>(spill) + (size_t)wave * (size_t)(bv.spill_stride / (2 * NWAVE));  // {index, cost lo, cost hi, -}
+    const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE));
+    auto snapshot_parent = [&](uint32_t X, int j0, bool check_j0, double bound, double &pc, uint32_t &pi, uint32_t &nnear,
                                uint32_t &ntests, uint32_t &tcells) {
         pc = f64_inf();
         pi = NONE;
         nnear = 0;
+        if (r2 == 0) return;
+        const int x = ux(X), y = uy(X);
+        const int cx0 = (x - rad < 0 ? 0 : x - rad) >> cshift, cx1 = (x + rad > W - 1 ? W - 1 : x + rad) >> cshift;
+        const int cy0 = (y - rad < 0 ? 0 : y - rad) >> cshift, cy1 = (y + rad > H - 1 ? H - 1 : y + rad) >> cshift;
+        const int ny = cy1 - cy0 + 1, ncr = (cx1 - cx0 + 1) * ny;
+        // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
+        auto screen_of = [](double c) -> float { return (float)c * (1.0f + 1.0e-6f) + 4.0e-3f; };
+        const float boundf = screen_of(bound);
+        const float FINF = __uint_as_float(0x7f800000u);
+        // the cells of the ball's bounding box: lane c (< ncr, first 64) holds cell c's fill count and record offset
+        uint32_t tcnt = 0, toff = 0;
+        if (lane < ncr) {
+            const int cell = (cx0 + lane / ny) * ncy + (cy0 + lane % ny);
+            tcnt = cellcnt[cell];
+            toff = (uint32_t)cell * (uint32_t)ccap;
+        }
         double lbc = -1.0;
         uint32_t lbi = 0;
-        const int nent = NWAVE * nsteps;  // mask words of this sample
-        for (;;) {                        // branch-and-bound rounds; one round unless the cheapest entry is blocked
+        for (int pass = 0;; ++pass) {
+            const bool collect = pass > 0;
             Top2 tt;
             tt.init();
-            uint32_t hits = 0;
-            // total flagged quads, processed QCAP at a time
-            uint32_t mycnt = 0;
-            auto midx = [&](int e) -> size_t { return ((size_t)(e % NWAVE) * nsteps_cap + (size_t)(e / NWAVE)) * BS + (size_t)k; };
-            for (int e = lane; e < nent; e += 64) mycnt += (uint32_t)__builtin_popcountll(masks[midx(e)]);
-            // exclusive prefix over lanes
-            uint32_t incl = mycnt;
-            {
-                // inclusive scan by DPP row_shr + row_bcast (same ladder as the reductions)
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
-            }
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const uint32_t excl = incl - mycnt;
-            for (uint32_t base = 0; base < total; base += QCAP) {
-                // stage 0: write the ids of flagged quads [base, base+QCAP) into the LDS list
-                {
-                    uint32_t pos = excl;
-                    for (int e = lane; e < nent; e += 64) {
-                        unsigned long long m = masks[midx(e)];
-                        const uint32_t w = (uint32_t)e % NWAVE, s = (uint32_t)e / NWAVE;
-                        while (m) {
-                            const uint32_t L = (uint32_t)__builtin_ctzll(m);
-                            m &= m - 1;
-                            if (pos >= base && pos < base + QCAP) qlist[pos - base] = s * TPB + w * 64 + L;
-                            ++pos;
+            float m1 = FINF, m2 = FINF;  // this lane's two cheapest verified entries, rounded up to f32
+            uint32_t hits = 0, nlist = 0;
+            // pass 0 only needs the two cheapest entries: once two are known, everything above the second (in f32, with
+            // margin) is screened out before any f64 work.  T is wave-uniform.
+            float T = boundf;
+            for (int c0 = 0; c0 < ncr; c0 += CG) {  // CG cells at a time: CG independent record loads in flight
+                uint32_t cnt[CG];
+                const u32x4 *rec[CG];
+                uint32_t maxc = 0;
+#pragma unroll
+                for (int g = 0; g < CG; ++g) {
+                    cnt[g] = 0;
+                    rec[g] = cellrec;
+                    if (c0 + g < ncr) {
+                        if (c0 + g < 64) {
+                            cnt[g] = (uint32_t)__builtin_amdgcn_readlane((int)tcnt, c0 + g);
+                            rec[g] = cellrec + (uint32_t)__builtin_amdgcn_readlane((int)toff, c0 + g);
+                        } else {  // more than 64 cells: a radius far beyond the cell size
+                            const int ci = c0 + g, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
+                            cnt[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cellcnt[cell]);
+                            rec[g] = cellrec + (size_t)cell * (size_t)ccap;
                         }
                     }
+                    maxc = cnt[g] > maxc ? cnt[g] : maxc;
                 }
-                const uint32_t cnt = (total - base) < (uint32_t)QCAP ? (total - base) : (uint32_t)QCAP;
-                // stage 1+2: evaluate the quads, price the hits
-                for (uint32_t p = (uint32_t)lane; p < cnt; p += 64) {
-                    const uint32_t qd = qlist[p];
-                    u32x4 v;
-                    if ((int)(qd / TPB) < lds_chunks)
-                        v = nodes_lds4[qd];
-                    else
-                        v = nodes_g4[qd];
-                    const uint32_t idx0 = qd * 4;
-                    const uint32_t d0 = dist2(v.x, X), d1 = dist2(v.y, X), d2 = dist2(v.z, X), d3 = dist2(v.w, X);
-                    const bool h0 = d0 < r2 && idx0 < (uint32_t)j0, h1 = d1 < r2 && idx0 + 1 < (uint32_t)j0,
-                               h2 = d2 < r2 && idx0 + 2 < (uint32_t)j0, h3 = d3 < r2 && idx0 + 3 < (uint32_t)j0;
-                    hits += (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
-                    // gather the four costs together, then price
-                    const double v0 = h0 ? vcost[idx0] : 0.0, v1 = h1 ? vcost[idx0 + 1] : 0.0, v2 = h2 ? vcost[idx0 + 2] : 0.0,
-                                 v3 = h3 ? vcost[idx0 + 3] : 0.0;
-                    if (h0) {
-                        const double cn = v0 + sqrt_u24(d0);
-                        if (cn < bound && !key_lt(cn, idx0, lbc, lbi)) tt.fold(cn, idx0);
+                for (uint32_t s0 = 0; s0 < maxc; s0 += 64) {
+                    const uint32_t s = s0 + (uint32_t)lane;
+                    u32x4 rc[CG];
+#pragma unroll
+                    for (int g = 0; g < CG; ++g) {
+                        rc[g] = u32x4{0x7fff7fffu, NONE, 0u, 0u};  // far away: never within the radius
+                        if (s < cnt[g]) rc[g] = rec[g][s];            // {xy, index, vcost}
                     }
-                    if (h1) {
-                        const double cn = v1 + sqrt_u24(d1);
-                        if (cn < bound && !key_lt(cn, idx0 + 1, lbc, lbi)) tt.fold(cn, idx0 + 1);
+                    bool dirty = false;
+#pragma unroll
+                    for (int g = 0; g < CG; ++g) {
+                        const uint32_t d2 = dist2(rc[g].x, X);
+                        const bool hit = d2 < r2 && (!check_j0 || rc[g].y < (uint32_t)j0);
+                        hits += hit ? 1u : 0u;
+                        const double V = __longlong_as_double((long long)(((unsigned long long)rc[g].w << 32) | rc[g].z));
+                        const bool maybe = hit && ((float)V + __builtin_amdgcn_sqrtf((float)d2) < T);  // never rejects a true candidate
+                        if (__ballot(maybe) == 0) continue;
+                        bool cand = false;
+                        double cn = 0.0;
+                        if (maybe) {
+                            cn = V + sqrt_u24(d2);
+                            cand = cn < bound && !key_lt(cn, rc[g].y, lbc, lbi);  // rrt.py:518, strict
+                        }
+                        if (cand) {
+                            tt.fold(cn, rc[g].y);
+                            const float cu = screen_of(cn);
+                            if (cu < m1) {
+                                m2 = m1;
+                                m1 = cu;
+                            } else if (cu < m2) {
+                                m2 = cu;
+                            }
+                        }
+                        dirty = true;
+                        if (collect) {
+                            const unsigned long long m = __ballot(cand);
+                            if (cand) {
+                                const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                                const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
+                                if (pos < clist_cap) clist[pos] = u32x4{rc[g].y, (uint32_t)cb, (uint32_t)(cb >> 32), 0u};
+                            }
+                            nlist += (uint32_t)__builtin_popcountll(m);
+                        }
                     }
-                    if (h2) {
-                        const double cn = v2 + sqrt_u24(d2);
-                        if (cn < bound && !key_lt(cn, idx0 + 2, lbc, lbi)) tt.fold(cn, idx0 + 2);
-                    }
-                    if (h3) {
-                        const double cn = v3 + sqrt_u24(d3);
-                        if (cn < bound && !key_lt(cn, idx0 + 3, lbc, lbi)) tt.fold(cn, idx0 + 3);
+                    if (dirty && !collect) {  // tighten the screen to (an upper bound of) the wave's second cheapest so far
+                        const float w1 = wave_min_f32_nonneg(m1);
+                        const float w2 = wave_min_f32_nonneg(m1 == w1 ? m2 : m1);
+                        T = w2 < boundf ? w2 : boundf;
                     }
                 }
             }
             nnear = wave_sum_u32(hits);
-            tt.wave_reduce();
-            // test in key order: the two cheapest are known; a third needs another decode round
-            if (tt.i1 == NONE) return;
-            int cc = 0;
-            bool ok = los_wave(og, H, node_xy(tt.i1), X, lane, cc);  // rrt.py:519
-            ntests += 1;
-            tcells += (uint32_t)cc;
-            if (ok) {
-                pc = tt.c1;
-                pi = tt.i1;
-                return;
+            if (!collect || nlist > clist_cap) {  // (a list that overflowed -- a huge radius -- is unusable: keep streaming, two tests per pass)
+                tt.wave_reduce();
+                if (tt.i1 == NONE) return;
+                int cc = 0;
+                bool ok = los_wave(og, H, node_xy(tt.i1), X, lane, cc);  // rrt.py:519
+                ntests += 1;
+                tcells += (uint32_t)cc;
+                if (ok) {
+                    pc = tt.c1;
+                    pi = tt.i1;
+                    return;
+                }
+                if (tt.i2 == NONE) return;
+                ok = los_wave(og, H, node_xy(tt.i2), X, lane, cc);
+                ntests += 1;
+                tcells += (uint32_t)cc;
+                if (ok) {
+                    pc = tt.c2;
+                    pi = tt.i2;
+                    return;
+                }
+                lbc = tt.c2;
+                lbi = tt.i2 + 1;
+                continue;  // both blocked: collect the rest
             }
-            if (tt.i2 == NONE) return;
-            ok = los_wave(og, H, node_xy(tt.i2), X, lane, cc);
-            ntests += 1;
-            tcells += (uint32_t)cc;
-            if (ok) {
-                pc = tt.c2;
-                pi = tt.i2;
-                return;
+            // consume the parked entries in key order
+            const uint32_t have = nlist;
+            for (;;) {
+                double bc = f64_inf();
+                uint32_t bi = NONE;
+                for (uint32_t p = (uint32_t)lane; p < have; p += 64) {
+                    const u32x4 e = clist[p];
+                    const double cn = __longlong_as_double((long long)(((unsigned long long)e.z << 32) | e.y));
+                    if (!key_lt(cn, e.x, lbc, lbi) && key_lt(cn, e.x, bc, bi)) {
+                        bc = cn;
+                        bi = e.x;
+                    }
+                }
+                wave_min_f64_idx(bc, bi);
+                if (bi == NONE) break;
+                int cc = 0;
+                const bool ok = los_wave(og, H, node_xy(bi), X, lane, cc);
+                ntests += 1;
+                tcells += (uint32_t)cc;
+                if (ok) {
+                    pc = bc;
+                    pi = bi;
+                    return;
+                }
+                lbc = bc;
+                lbi = bi + 1;
             }
-            lbc = tt.c2;
-            lbi = tt.i2 + 1;
+            return;  // every remaining entry was tried
         }
     };
 
@@ -317,12 +371,12 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 xv = samples[i0 + lane];
             }
         }
-        uint32_t X[BS], xs16[BS];
+        uint32_t xs16[BS];
 #pragma unroll
         for (int k = 0; k < BS; ++k) {
-            X[k] = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
-            if (k >= nb) X[k] = X[0];
-            xs16[k] = X[k] << 4;
+            uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
+            if (k >= nb) X = (uint32_t)__builtin_amdgcn_readlane((int)xv, 0);
+            xs16[k] = X << 4;
         }
 
         // ---------------- A: scan the snapshot for all samples of the block ----------------
@@ -337,11 +391,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 for (int c = 0; c < nl; ++c) {
                     u32x4 nxt = cur;
                     if (c + 1 < nl) nxt = nodes_lds4[(c + 1) * TPB + t];
-                    RRT_LDS unsigned long long *row = masks + ((size_t)wave * nsteps_cap + c) * BS;
-                    if (star)
-                        block_scan_step<true>(cur, xs16, best, (uint32_t)c << 2, r2key, row, lane);
-                    else
-                        block_scan_step<false>(cur, xs16, best, (uint32_t)c << 2, r2key, row, lane);
+                    block_scan_step(cur, xs16, best, (uint32_t)c << 2);
                     cur = nxt;
                 }
             }
@@ -350,24 +400,26 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 for (int c = nl; c < nsteps; ++c) {
                     u32x4 nxt = cur;
                     if (c + 1 < nsteps) nxt = nodes_g4[(c + 1) * TPB + t];
-                    RRT_LDS unsigned long long *row = masks + ((size_t)wave * nsteps_cap + c) * BS;
-                    if (star)
-                        block_scan_step<true>(cur, xs16, best, (uint32_t)c << 2, r2key, row, lane);
-                    else
-                        block_scan_step<false>(cur, xs16, best, (uint32_t)c << 2, r2key, row, lane);
+                    block_scan_step(cur, xs16, best, (uint32_t)c << 2);
                     cur = nxt;
                 }
             }
-            // per sample: wave minimum (lowest index among equal distance), gathered into lanes 0..15
+            // per sample: wave minimum of d2, lowest index among the lanes that hold it (a lane's best key already
+            // carries its lowest such index); gathered into lanes 0..15
             uint32_t gd = NONE, gi = NONE;
 #pragma unroll
             for (int k = 0; k < BS; ++k) {
-                uint32_t kd = best[k] >> 8;
-                const uint32_t tag = best[k] & 0xffu;
+                const uint32_t key = best[k];
+                const uint32_t d2m = wave_min_u32(key) >> 8;
+                const uint32_t tag = key & 0xffu;
                 uint32_t ki = (tag >> 2) * (uint32_t)CHUNK + 4u * (uint32_t)t + (tag & 3u);
-                wave_min_key_idx(kd, ki);
+                const unsigned long long tie = __ballot((key >> 8) == d2m);
+                if (__builtin_popcountll(tie) == 1)
+                    ki = (uint32_t)__builtin_amdgcn_readlane((int)ki, (int)__builtin_ctzll(tie));
+                else
+                    ki = wave_min_u32((key >> 8) == d2m ? ki : NONE);
                 if (lane == k) {
-                    gd = kd;
+                    gd = d2m;
                     gi = ki;
                 }
             }
@@ -384,7 +436,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         // ---------------- B: owner phase, wave k resolves sample k against the snapshot ----------------
         if (wave < nb) {
             const int k = wave;
-            const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);  // every wave loaded the same xv
+            const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);  // every wave holds the same xv
             uint32_t d2s = NONE, vs = NONE;
             if (lane < NWAVE) {
                 const u32x2 v = ((RRT_LDS u32x2 *)nnx)[k * NWAVE + lane];
@@ -398,14 +450,15 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             int cells = 0;
             const bool free_s = los_wave(og, H, node_xy(vs), Xk, lane, cells);
             // earlier samples of this block that could interact once inserted
-            uint32_t xo = (lane < k) ? xq_lds[lane] : Xk;
+            const uint32_t xo = (lane < k) ? xq_lds[lane] : Xk;
             const uint32_t dk = dist2(xo, Xk);
             const uint32_t nnmask = (uint32_t)__ballot(lane < k && dk < d2s);
             const uint32_t rmask = (uint32_t)__ballot(lane < k && star && dk < r2);
             const uint32_t dupmask = (uint32_t)__ballot(lane < k && xo == Xk);
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
-            if (star) snapshot_parent(k, Xk, j0, nsteps, Vs + sqrt_u32(d2s), pc, pi, nnear, ntests, tcells);
+            const double cnear_s = Vs + sqrt_u32(d2s);
+            if (star) snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);  // no block node is in the cells yet
             if (lane == 0) {
                 BRec r;
                 r.d2s = d2s;
@@ -413,14 +466,14 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.los_s = (free_s ? 0x80000000u : 0u) | (uint32_t)cells;
                 r.flags = (bm_word >> (cell & 31)) & 1u;
                 r.Vs = Vs;
-                r.pc = pc;
-                r.pi = pi;
+                r.cbest = (pi != NONE) ? pc : cnear_s;
+                r.vbest = (pi != NONE) ? pi : vs;
                 r.pstat = (ntests << 20) | (tcells & 0xfffffu);
                 r.nnmask = nnmask;
                 r.rmask = rmask;
                 r.dupmask = dupmask;
                 r.nnear = nnear;
-                r.pad[0] = r.pad[1] = 0;
+                r.pc = pc;
                 brec[k] = r;
             }
         }
@@ -428,30 +481,91 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         __syncthreads();
         STAMP(3);
 
-        // ---------------- C: commit in sample order (wave 0) ----------------
+        // ---------------- C: commit (wave 0) ----------------
         if (wave == 0) {
-            uint32_t acc_mask = 0;
-            int k = 0;
-            for (; k < nb; ++k) {
-                const BRec r = brec[k];
-                const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
-                const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
-                uint32_t vn = r.vs, d2n = r.d2s;
-                double Vn = r.Vs;
-                bool nocoll = (r.los_s >> 31) != 0;
-                uint32_t cells = r.los_s & 0x7fffffffu;
-                bool dup = (r.flags & 1u) != 0;
-                double pc = r.pc;
-                uint32_t pi = r.pi, nnear = r.nnear;
-                uint32_t ntests = r.pstat >> 20, tcells = r.pstat & 0xfffffu;
-                const uint32_t inter = (r.nnmask | r.rmask | r.dupmask) & acc_mask;
-                const uint32_t xo = (lane < BS) ? xq_lds[lane] : Xk;  // lane kk: sample kk
-                const uint32_t dk = dist2(xo, Xk);
-                const uint32_t lbit = (lane < BS) ? (1u << lane) : 0u;
-                if (inter) {
-                    // re-resolve against snapshot + inserted block nodes
-                    dup = dup || ((r.dupmask & acc_mask) != 0);
-                    const uint32_t nm = r.nnmask & acc_mask;
+            BRec r;
+            r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnmask = r.rmask = r.dupmask = r.nnear = 0;
+            r.Vs = r.cbest = r.pc = 0.0;
+            if (lane < nb) r = brec[lane];  // lane k: sample k
+            const bool acc0 = lane < nb && (r.los_s >> 31) != 0 && (r.flags & 1u) == 0;  // accepted if nothing in the block interferes
+            const uint32_t M = r.nnmask | r.rmask | r.dupmask;
+            const bool goalhit = informed && lane < nb && dist2(xv, xg) < goal_d2;
+            const uint32_t lbit = (lane < BS) ? (1u << lane) : 0u;
+            const uint32_t ltmask = lbit - 1u;  // lanes below (meaningless for lanes >= BS, which never use it)
+            uint32_t acc_exact = 0;
+            int cur = 0;
+            bool cut = false;
+            while (cur < nb && !cut) {
+                // ---- the run of samples [cur, k0) that commit together ----
+                const uint32_t pend = (uint32_t)__ballot(acc0 && lane >= cur);
+                const uint32_t Aopt = acc_exact | (pend & ltmask);  // exact below cur, optimistic in [cur, lane)
+                const bool slow = lane >= cur && lane < nb && ((M & Aopt) != 0 || (goalhit && acc0));
+                const unsigned long long bad = __ballot(slow);
+                int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
+                {
+                    const uint32_t range = ((1u << k0) - 1u) & ~((1u << cur) - 1u);  // k0 <= 16
+                    if (j + __builtin_popcount(pend & range) > n) k0 = cur;  // would overfill: take the exact serial path
+                }
+                if (k0 > cur) {
+                    const uint32_t range = ((1u << k0) - 1u) & ~((1u << cur) - 1u);
+                    const uint32_t racc = pend & range;
+                    const bool inr = lane >= cur && lane < k0;
+                    const bool myacc = inr && acc0;
+                    const int jmine = j + __builtin_popcount(racc & ltmask);  // j as this sample sees it
+                    if (inr) {
+                        a_sum_j += (unsigned long long)jmine;
+                        a_cells_nn += (unsigned long long)(r.los_s & 0x7fffffffu);
+                        if (logs) {
+                            const size_t o = (size_t)q * bv.n_cap + i0 + lane;
+                            bv.nearest_log[o] = (int32_t)r.vs;
+                            bv.accept_log[o] = (uint8_t)myacc;
+                            bv.cbest_log[o] = ell ? c_ell : __longlong_as_double(0x7ff8000000000000ll);
+                            bv.j_log[o] = jmine;
+                        }
+                    }
+                    if (myacc) {
+                        if (star) {
+                            a_near += r.nnear;
+                            a_los_cand += r.pstat >> 20;
+                            a_cells_cand += r.pstat & 0xfffffu;
+                        }
+                        const uint32_t cellbit = (uint32_t)ux(xv) * (uint32_t)H + (uint32_t)uy(xv);
+                        nodes_g[jmine] = xv;
+                        if (jmine < lds_nodes) nodes_lds[jmine] = xv;
+                        vcost[jmine] = r.cbest;
+                        parent[jmine] = (int32_t)r.vbest;
+                        atomicOr(&bitmap[cellbit >> 5], 1u << (cellbit & 31));  // rrt.py:426
+                        newcost[lane] = r.cbest;
+                        if (star) {
+                            const int c = cell_of(xv);
+                            const uint32_t slot = __hip_atomic_fetch_add(&cellcnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned long long cb = (unsigned long long)__double_as_longlong(r.cbest);
+                            u32x4 rc = {xv, (uint32_t)jmine, (uint32_t)cb, (uint32_t)(cb >> 32)};
+                            cellrec[(size_t)c * (size_t)ccap + slot] = rc;
+                        }
+                    }
+                    acc_exact |= racc;
+                    j += __builtin_popcount(racc);
+                    cur = k0;
+                }
+                if (cur >= nb) break;
+                // ---- sample `cur` on its own: re-resolve against snapshot + inserted block nodes ----
+                {
+                    const int k = cur;
+                    const BRec rk = brec[k];
+                    const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
+                    const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
+                    uint32_t vn = rk.vs, d2n = rk.d2s;
+                    double Vn = rk.Vs;
+                    bool nocoll = (rk.los_s >> 31) != 0;
+                    uint32_t cells = rk.los_s & 0x7fffffffu;
+                    double pc = rk.pc;
+                    uint32_t pi = (rk.pc < f64_inf()) ? rk.vbest : NONE, nnear = rk.nnear;
+                    uint32_t ntests = rk.pstat >> 20, tcells = rk.pstat & 0xfffffu;
+                    const uint32_t xo = (lane < BS) ? xq_lds[lane] : Xk;  // lane kk: sample kk
+                    const uint32_t dk = dist2(xo, Xk);
+                    const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_exact) != 0;
+                    const uint32_t nm = rk.nnmask & acc_exact;
                     bool nn_inblock = false;
                     if (nm) {  // nearest is an inserted block node: smallest distance, earliest sample on ties
                         uint32_t kd = (nm & lbit) ? dk : NONE;
@@ -459,34 +573,37 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         wave_min_key_idx(kd, kk);
                         nn_inblock = true;
                         d2n = kd;
-                        vn = (uint32_t)j0 + (uint32_t)__builtin_popcount(acc_mask & ((1u << kk) - 1u));
+                        vn = (uint32_t)j0 + (uint32_t)__builtin_popcount(acc_exact & ((1u << kk) - 1u));
                         Vn = newcost[kk];
                         int cc = 0;
                         nocoll = los_wave(og, H, (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk), Xk, lane, cc);  // rrt.py:424
                         cells = (uint32_t)cc;
                     }
-                    if (star && nocoll && !dup && j != n) {
-                        const double cnear = Vn + sqrt_u32(d2n);
+                    const bool acc = nocoll && !dup && j != n;  // rrt.py:425
+                    uint32_t vbest = vn;
+                    double cbest = Vn + sqrt_u32(d2n);
+                    if (acc && star) {
+                        const double cnear = cbest;
                         if (nn_inblock) {
-                            const double cnear_s = r.Vs + sqrt_u32(r.d2s);
+                            const double cnear_s = rk.Vs + sqrt_u32(rk.d2s);
                             if (cnear > cnear_s) {  // entries between the two bounds were never priced: redo the snapshot part
                                 ntests = 0;
                                 tcells = 0;
-                                snapshot_parent(k, Xk, j0, nsteps, cnear, pc, pi, nnear, ntests, tcells);
+                                snapshot_parent(Xk, j0, true, cnear, pc, pi, nnear, ntests, tcells);
                             } else if (pi != NONE && !(pc < cnear)) {
                                 pc = f64_inf();
                                 pi = NONE;
                             }
                         }
                         // inserted block nodes within r_rewire, in (cost, index) order, while they beat the snapshot's best
-                        uint32_t rm = r.rmask & acc_mask;
+                        uint32_t rm = rk.rmask & acc_exact;
                         nnear += (uint32_t)__builtin_popcount(rm);
                         while (rm) {
                             double cn = f64_inf();
                             uint32_t ci = NONE;
                             if (rm & lbit) {
                                 cn = newcost[lane] + sqrt_u32(dk);
-                                ci = (uint32_t)j0 + (uint32_t)__builtin_popcount(acc_mask & (lbit - 1u));
+                                ci = (uint32_t)j0 + (uint32_t)__builtin_popcount(acc_exact & ltmask);
                                 if (!(cn < cnear)) {
                                     cn = f64_inf();
                                     ci = NONE;
@@ -494,12 +611,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             }
                             wave_min_f64_idx(cn, ci);
                             if (ci == NONE || !key_lt(cn, ci, pc, pi)) break;
-                            // which sample is node ci
-                            const uint32_t rank = ci - (uint32_t)j0;
-                            uint32_t kk = 0;
+                            uint32_t kk = 0;  // which sample is node ci
                             {
-                                uint32_t am = acc_mask;
-                                for (uint32_t c = 0; c < rank; ++c) am &= am - 1;
+                                uint32_t am = acc_exact;
+                                for (uint32_t c = 0; c < ci - (uint32_t)j0; ++c) am &= am - 1;
                                 kk = (uint32_t)__builtin_ctz(am);
                             }
                             int cc = 0;
@@ -513,70 +628,68 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             }
                             rm &= ~(1u << kk);
                         }
-                    }
-                }
-                const bool acc = nocoll && !dup && j != n;  // rrt.py:425
-                sum_j += (unsigned long long)j;
-                sum_cells_nn += (unsigned long long)cells;
-                if (logs && lane == 0) {
-                    bv.nearest_log[(size_t)q * bv.n_cap + i0 + k] = (int32_t)vn;
-                    bv.accept_log[(size_t)q * bv.n_cap + i0 + k] = (uint8_t)acc;
-#ifdef RRT_DEBUG_NNEAR
-                    bv.cbest_log[(size_t)q * bv.n_cap + i0 + k] = (double)nnear + (inter ? 0.5 : 0.0);
-#else
-                    bv.cbest_log[(size_t)q * bv.n_cap + i0 + k] = ell ? c_ell : __longlong_as_double(0x7ff8000000000000ll);
-#endif
-                    bv.j_log[(size_t)q * bv.n_cap + i0 + k] = j;
-                }
-                bool cut = false;
-                if (acc) {
-                    uint32_t vbest = vn;
-                    double cbest = Vn + sqrt_u32(d2n);
-                    if (star) {
-                        sum_near += nnear;
-                        n_los_cand += ntests;
-                        sum_cells_cand += tcells;
                         if (pi != NONE) {
                             vbest = pi;
                             cbest = pc;
                         }
                     }
                     if (lane == 0) {
-                        nodes_g[j] = Xk;
-                        if (j < lds_nodes) nodes_lds[j] = Xk;
-                        vcost[j] = cbest;
-                        parent[j] = (int32_t)vbest;
-                        atomicOr(&bitmap[cell >> 5], 1u << (cell & 31));  // rrt.py:426
-                        newcost[k] = cbest;
-                    }
-                    if (informed && dist2(Xk, xg) < goal_d2) {  // rrt.py:744-745
-                        const bool first = nsoln == 0;
-                        nsoln++;
-                        if (cbest < cmin_soln) {
-                            cmin_soln = cbest;
-                            vbest_soln = j;
-                            c_ell = cmin_soln + sqrt_u32(dist2(xg, Xk));
-                            cut = true;  // the ellipse changed: later samples of this block are stale (rrt.py:698-700)
+                        a_sum_j += (unsigned long long)j;
+                        a_cells_nn += (unsigned long long)cells;
+                        if (logs) {
+                            const size_t o = (size_t)q * bv.n_cap + i0 + k;
+                            bv.nearest_log[o] = (int32_t)vn;
+                            bv.accept_log[o] = (uint8_t)acc;
+                            bv.cbest_log[o] = ell ? c_ell : __longlong_as_double(0x7ff8000000000000ll);
+                            bv.j_log[o] = j;
                         }
-                        if (first) cut = true;  // sampling switches from free space to the ellipse (rrt.py:695)
                     }
-                    acc_mask |= 1u << k;
-                    j++;
-                }
-                if (cut) {
-                    ++k;
-                    break;
+                    if (acc) {
+                        if (lane == 0) {
+                            if (star) {
+                                a_near += nnear;
+                                a_los_cand += ntests;
+                                a_cells_cand += tcells;
+                            }
+                            nodes_g[j] = Xk;
+                            if (j < lds_nodes) nodes_lds[j] = Xk;
+                            vcost[j] = cbest;
+                            parent[j] = (int32_t)vbest;
+                            atomicOr(&bitmap[cell >> 5], 1u << (cell & 31));  // rrt.py:426
+                            newcost[k] = cbest;
+                            if (star) {
+                                const int c = cell_of(Xk);
+                                const uint32_t slot = __hip_atomic_fetch_add(&cellcnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                const unsigned long long cb = (unsigned long long)__double_as_longlong(cbest);
+                                u32x4 rc = {Xk, (uint32_t)j, (uint32_t)cb, (uint32_t)(cb >> 32)};
+                                cellrec[(size_t)c * (size_t)ccap + slot] = rc;
+                            }
+                        }
+                        if (informed && dist2(Xk, xg) < goal_d2) {  // rrt.py:744-745
+                            const bool first = nsoln == 0;
+                            nsoln++;
+                            if (cbest < cmin_soln) {  // np.argmin keeps the first minimum (rrt.py:632)
+                                cmin_soln = cbest;
+                                vbest_soln = j;
+                                c_ell = cmin_soln + sqrt_u32(dist2(xg, Xk));
+                                cut = true;  // the ellipse changed: later samples of this block are stale (rrt.py:698-700)
+                            }
+                            if (first) cut = true;  // sampling switches from free space to the ellipse (rrt.py:695)
+                        }
+                        acc_exact |= 1u << k;
+                        j++;
+                    }
+                    cur = k + 1;
                 }
             }
-            i = i0 + k;
+            i = i0 + cur;
             if (lane == 0) {
                 BlkState b;
                 b.i = i;
                 b.j = j;
                 b.nsoln = nsoln;
                 b.vbest_soln = vbest_soln;
-                b.i_switch = i_switch;
-                b.status = status;
+                b.pad0 = b.pad1 = 0;
                 b.cmin_soln = cmin_soln;
                 b.c_ell = c_ell;
                 blk = b;
@@ -595,6 +708,15 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         }
     }
 
+    // cell fill counts back to HBM (a resumed launch reloads them); fold wave 0's statistics
+    for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
+    if (wave == 0 && lane < BS) {
+        statred[lane * 5 + 0] = a_sum_j;
+        statred[lane * 5 + 1] = a_cells_nn;
+        statred[lane * 5 + 2] = a_near;
+        statred[lane * 5 + 3] = a_cells_cand;
+        statred[lane * 5 + 4] = a_los_cand;
+    }
     __syncthreads();
 
     // ---------------- go2goal (rrt.py:311-332): same branch and bound as rrt_expand_kernel ----------------
@@ -632,13 +754,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             }
             if (lane == 0) bslots[(round & 1) * NWAVE + wave] = bs;
             __syncthreads();
-            BSlot r;
-            r.pc = r.uc = f64_inf();
-            r.pi = r.ui = NONE;
-            if (lane < NWAVE) r = bslots[(round & 1) * NWAVE + lane];
+            BSlot rr;
+            rr.pc = rr.uc = f64_inf();
+            rr.pi = rr.ui = NONE;
+            if (lane < NWAVE) rr = bslots[(round & 1) * NWAVE + lane];
             ++round;
-            double npc = r.pc, uc = r.uc;
-            uint32_t npi = r.pi, ui = r.ui;
+            double npc = rr.pc, uc = rr.uc;
+            uint32_t npi = rr.pi, ui = rr.ui;
             wave_min_f64_idx(npc, npi);
             wave_min_f64_idx(uc, ui);
             if (key_lt(npc, npi, pc, pi)) {
@@ -663,6 +785,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     }
 
     if (t == 0) {
+        unsigned long long s[5] = {0, 0, 0, 0, 0};
+        for (int l = 0; l < BS; ++l)
+            for (int c = 0; c < 5; ++c) s[c] += statred[l * 5 + c];
         D->status = status;
         D->i = i;
         D->j = j;
@@ -672,11 +797,11 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         D->vgoal = vgoal;
         D->found = found;
         D->i_switch = i_switch;
-        D->sum_j = sum_j;
-        D->sum_cells_nn = sum_cells_nn;
-        D->sum_near = sum_near;
-        D->sum_cells_cand = sum_cells_cand;
-        D->n_los_cand = n_los_cand;
+        D->sum_j += s[0];
+        D->sum_cells_nn += s[1];
+        D->sum_near += s[2];
+        D->sum_cells_cand += s[3];
+        D->n_los_cand += s[4];
 #ifdef RRT_STAMPS
         for (int k = 0; k < 6; ++k) D->cyc[k] = cyc[k];
 #endif

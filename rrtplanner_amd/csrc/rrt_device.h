@@ -63,6 +63,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Wave-wide minimum of non-negative floats (their bit patterns order like unsigned integers).
+__device__ __forceinline__ float wave_min_f32_nonneg(float v) { return __uint_as_float(wave_min_u32(__float_as_uint(v))); }
+
 // Lexicographic wave minimum of (key, idx): smallest key, lowest idx among equal keys.
 __device__ __forceinline__ void wave_min_key_idx(uint32_t &key, uint32_t &idx) {
     uint32_t mk = wave_min_u32(key);

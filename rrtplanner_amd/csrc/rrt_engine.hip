@@ -45,6 +45,9 @@ struct rrt_batch {
     int32_t *d_parent = nullptr, *d_nearest_log = nullptr, *d_j_log = nullptr;
     uint8_t *d_accept_log = nullptr;
     uint2 *d_spill = nullptr;
+    uint4 *d_cellrec = nullptr;    // block kernel: near-set records, [Q][rec_stride]
+    uint32_t *d_cellcnt = nullptr; // [Q][MAX_CELLS]
+    int64_t rec_stride = 0;
     unsigned char *d_slab = nullptr;  // result slab: [vcost f64 | nodes u32 | parent i32], each [Q][node_stride]
     size_t slab_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -114,12 +117,39 @@ extern "C" int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, 
     return RRT_OK;
 }
 
+// Near-set record grid of one query: cell edge 2^shift pixels, about half the rewire radius, at most MAX_CELLS
+// cells.  A cell holds at most 4^shift + 1 nodes (one per pixel, plus xstart once more: rrt.py:425) and at most n + 1.
+static void cell_geometry(int W, int H, int64_t r2, int n, int &shift, int &ncx, int &ncy, int &cap) {
+    double r = std::sqrt((double)(r2 < 1 ? 1 : r2));
+    shift = 4;
+    while ((1 << (shift + 1)) <= r / 2.0 && shift < 11) ++shift;
+    for (;; ++shift) {
+        ncx = (W + (1 << shift) - 1) >> shift;
+        ncy = (H + (1 << shift) - 1) >> shift;
+        if ((long long)ncx * ncy <= MAX_CELLS) break;
+    }
+    long long c = (1LL << (2 * shift)) + 1;
+    cap = (int)(c < (long long)n + 1 ? c : (long long)n + 1);
+}
+
+static int64_t cell_records_needed(int W, int H, int n) {
+    int64_t best = 0;
+    for (int s = 4; s <= 11; ++s) {
+        const int64_t ncx = (W + (1 << s) - 1) >> s, ncy = (H + (1 << s) - 1) >> s;
+        if (ncx * ncy > MAX_CELLS) continue;
+        int64_t c = (1LL << (2 * s)) + 1;
+        if (c > (int64_t)n + 1) c = (int64_t)n + 1;
+        if (ncx * ncy * c > best) best = ncx * ncy * c;
+    }
+    return best;
+}
+
 extern "C" int rrt_batch_destroy(rrt_batch *b) {
     if (!b) return RRT_OK;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *ptrs[] = {b->d_desc,  b->d_samples,   b->d_slab,        b->d_bitmap, b->d_unitball,
-                    b->d_spill, b->d_cbest_log, b->d_nearest_log, b->d_j_log,  b->d_accept_log};
+    void *ptrs[] = {b->d_desc,  b->d_samples,   b->d_slab,        b->d_bitmap, b->d_unitball,  b->d_cellrec,
+                    b->d_spill, b->d_cbest_log, b->d_nearest_log, b->d_j_log,  b->d_accept_log, b->d_cellcnt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -147,14 +177,15 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->bitmap_words = (int32_t)(((size_t)ctx->W * ctx->H + 31) / 32);
     int chunks = (n_cap + 1 + CHUNK - 1) / CHUNK;
     b->spill_stride = chunks * CHUNK;  // 256 overflow entries per wave and node chunk; also go2goal's cost array
-    {   // block kernel LDS: [node cache | masks 2 KiB per 4096-node step | quad lists 32 KiB]
-        const size_t budget = (size_t)ctx->max_lds - 6144;  // static LDS of the kernel
-        const size_t fixed = (size_t)NWAVE * chunks * BS * sizeof(unsigned long long) + (size_t)NWAVE * QCAP * sizeof(uint32_t);
-        b->use_block = !(flags & RRT_FLAG_SERIAL) && fixed + (size_t)CHUNK * sizeof(uint32_t) <= budget;
+    {   // block kernel LDS: [node cache | cell fill counts 16 KiB]
+        const size_t budget = (size_t)ctx->max_lds - 8192;  // static LDS of the kernel
+        const size_t fixed = (size_t)MAX_CELLS * sizeof(uint32_t);
+        b->use_block = !(flags & RRT_FLAG_SERIAL);
         if (b->use_block) {
             int nc = (int)((budget - fixed) / ((size_t)CHUNK * sizeof(uint32_t)));
             b->blk_lds_chunks = nc > chunks ? chunks : nc;
             b->blk_lds_bytes = fixed + (size_t)b->blk_lds_chunks * CHUNK * sizeof(uint32_t);
+            b->rec_stride = cell_records_needed(ctx->W, ctx->H, n_cap);
         }
     }
     b->lds_chunks = chunks < 1 ? 1 : (chunks > MAX_LDS_CHUNKS ? MAX_LDS_CHUNKS : chunks);
@@ -178,6 +209,10 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->d_parent = reinterpret_cast<int32_t *>(b->d_slab + q * b->node_stride * (sizeof(double) + sizeof(uint32_t)));
     ALLOC(b->d_bitmap, q * b->bitmap_words * sizeof(uint32_t));
     ALLOC(b->d_spill, q * b->spill_stride * sizeof(uint2));
+    if (b->use_block) {
+        ALLOC(b->d_cellrec, q * (size_t)b->rec_stride * sizeof(uint4));
+        ALLOC(b->d_cellcnt, q * (size_t)MAX_CELLS * sizeof(uint32_t));
+    }
     if (flags & RRT_FLAG_LOGS) {
         ALLOC(b->d_nearest_log, q * n_cap * sizeof(int32_t));
         ALLOC(b->d_accept_log, q * n_cap * sizeof(uint8_t));
@@ -242,6 +277,7 @@ extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu)
     d.r2_rewire = (uint32_t)(qu->r2_rewire < 0 ? 0 : (qu->r2_rewire > cap ? cap : qu->r2_rewire));
     d.goal_d2 = (uint32_t)(qu->goal_d2 < 0 ? 0 : (qu->goal_d2 > cap ? cap : qu->goal_d2));
     for (int k = 0; k < 4; ++k) d.C[k] = qu->C[k];
+    cell_geometry(W, H, (int64_t)d.r2_rewire, b->n_cap, d.cell_shift, d.ncx, d.ncy, d.cell_cap);
     arm_desc(d);
     HIPCHK(ctx, hipMemcpyAsync(b->d_samples + (size_t)q * b->n_cap, b->stage.data(), (size_t)qu->n * sizeof(uint32_t),
                                hipMemcpyHostToDevice, ctx->stream));
@@ -302,6 +338,9 @@ static BatchView make_view(rrt_batch *b) {
     v.bitmap_words = b->bitmap_words;
     v.lds_chunks = b->lds_chunks;
     v.spill_stride = b->spill_stride;
+    v.cellrec = b->d_cellrec;
+    v.cellcnt = b->d_cellcnt;
+    v.rec_stride = b->rec_stride;
     return v;
 }
 

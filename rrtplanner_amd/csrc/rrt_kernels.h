@@ -38,6 +38,7 @@ struct QDesc {
     uint32_t r2_rewire, goal_d2;
     double C[4];
     int32_t ub_offset, ub_count;
+    int32_t cell_shift, ncx, ncy, cell_cap;  // block kernel: near-set record grid of this query (cell = 2^shift pixels)
     int32_t status, i, j, nsoln, vbest_soln, vgoal, found, i_switch;
     double cmin_soln;
     unsigned long long sum_j, sum_cells_nn, sum_near, sum_cells_cand, n_los_cand;
@@ -60,7 +61,12 @@ struct BatchView {
     const uint8_t *og;        // (W,H) x-major occupancy, != 0 is obstacle
     int32_t W, H;
     int32_t n_cap, node_stride, bitmap_words, lds_chunks, spill_stride;
+    uint4 *cellrec;           // [Q][rec_stride]    block kernel: per-cell arrays of {xy, index, vcost} records
+    uint32_t *cellcnt;        // [Q][MAX_CELLS]     fill counts of the cells
+    int64_t rec_stride;
 };
+
+constexpr int MAX_CELLS = 4096;  // cells per query (their fill counts live in LDS: 16 KiB)
 
 // Near set of one wave: every wave keeps the within-radius nodes of its own stripe in its own LDS
 // region (WCAP entries {idx, d2}, overflow to its own HBM region) and later prices them itself, so
@@ -644,6 +650,13 @@ __global__ void rrt_init_kernel(BatchView bv) {
     const uint32_t n0 = pack_xy(D->xs[0], D->xs[1]);
     for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < bv.node_stride; k += (int)(gridDim.x * blockDim.x))
         bv.nodes[(size_t)q * bv.node_stride + k] = n0;
+    if (bv.cellcnt) {  // near-set record grid: empty cells, then node 0 in its cell
+        const int c0 = (D->xs[0] >> D->cell_shift) * D->ncy + (D->xs[1] >> D->cell_shift);
+        for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < MAX_CELLS; k += (int)(gridDim.x * blockDim.x))
+            bv.cellcnt[(size_t)q * MAX_CELLS + k] = (k == c0) ? 1u : 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            bv.cellrec[(size_t)q * (size_t)bv.rec_stride + (size_t)c0 * (size_t)D->cell_cap] = make_uint4(n0, 0u, 0u, 0u);  // vcost 0.0
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         bv.vcost[(size_t)q * bv.node_stride] = 0.0;
         bv.parent[(size_t)q * bv.node_stride] = -1;

@@ -1,0 +1,89 @@
+// Throughput of candidate (node, sample) key computations on gfx950, whole workgroup (16 waves / CU), timed with HIP events.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define LDSP __attribute__((address_space(3)))
+constexpr int B = 16;
+
+template <int VAR> __device__ __forceinline__ uint32_t key1(uint32_t n, uint32_t q, int qx, int qy, uint32_t tag) {
+    if (VAR == 0) {  // pk_sub + dot2 (3-operand)
+        uint32_t d, r;
+        asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(n), "s"(q));
+        asm("v_dot2_i32_i16 %0, %1, %1, %2" : "=v"(r) : "v"(d), "s"(tag));
+        return r;
+    } else if (VAR == 1) {  // 2 sub + 2 mad_i24
+        int dx = (int)(n & 0xffff) - qx, dy = (int)(n >> 16) - qy;
+        return (uint32_t)(__mul24(dx, dx) + __mul24(dy, dy)) + tag;
+    } else {  // float
+        float dx = (float)(n & 0xffff) - (float)qx, dy = (float)(n >> 16) - (float)qy;
+        return (uint32_t)__builtin_fmaf(dy, dy, dx * dx) + tag;
+    }
+}
+
+template <int VAR>
+__global__ __launch_bounds__(1024) void k(const uint32_t* nodes, int nchunks, int reps, const uint32_t* queries, uint32_t* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LDSP uint32_t* l = (LDSP uint32_t*)smem;
+    const LDSP u32x4* l4 = (const LDSP u32x4*)smem;
+    int t = threadIdx.x;
+    for (int k = t; k < nchunks * 4096; k += 1024) l[k] = nodes[k];
+    __syncthreads();
+    uint32_t acc = 0;
+    for (int r = 0; r < reps; ++r) {
+        uint32_t q[B]; int qx[B], qy[B];
+#pragma unroll
+        for (int s = 0; s < B; ++s) { q[s] = __builtin_amdgcn_readfirstlane(queries[(r * B + s) & 1023]); qx[s] = q[s] & 0xffff; qy[s] = q[s] >> 16; }
+        uint32_t best[B];
+#pragma unroll
+        for (int s = 0; s < B; ++s) best[s] = 0xffffffffu;
+        u32x4 cur = l4[t];
+        for (int c = 0; c < nchunks; ++c) {
+            u32x4 nxt = cur;
+            if (c + 1 < nchunks) nxt = l4[(c + 1) * 1024 + t];
+            uint32_t n0 = cur.x << 4, n1 = cur.y << 4, n2 = cur.z << 4, n3 = cur.w << 4;
+            uint32_t tag = (uint32_t)c << 2;
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                uint32_t k0 = key1<VAR>(n0, q[s], qx[s], qy[s], tag), k1 = key1<VAR>(n1, q[s], qx[s], qy[s], tag + 1),
+                         k2 = key1<VAR>(n2, q[s], qx[s], qy[s], tag + 2), k3 = key1<VAR>(n3, q[s], qx[s], qy[s], tag + 3);
+                best[s] = min(min(best[s], k0), min(min(k1, k2), k3));
+            }
+            cur = nxt;
+        }
+#pragma unroll
+        for (int s = 0; s < B; ++s) acc ^= best[s] * (s + 1);
+    }
+    out[blockIdx.x * 1024 + t] = acc;
+}
+
+int main() {
+    const int nchunks = 6, reps = 400;
+    std::vector<uint32_t> h(nchunks * 4096), hq(1024);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = ((uint32_t)(i * 2654435761u) & 0x07ff) | ((((uint32_t)(i * 40503u) >> 3) & 0x07ff) << 16);
+    for (size_t i = 0; i < hq.size(); ++i) hq[i] = ((((uint32_t)(i * 7919u) & 0x07ff) << 4)) | (((((uint32_t)(i * 104729u) >> 2) & 0x07ff) << 4) << 16);
+    uint32_t *d, *out, *dq;
+    (void)hipMalloc(&d, h.size() * 4); (void)hipMalloc(&out, 256 * 1024 * 4); (void)hipMalloc(&dq, 4096);
+    (void)hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dq, hq.data(), 4096, hipMemcpyHostToDevice);
+    size_t lds = nchunks * 16384;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto run = [&](auto kern, const char* name) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (int blocks : {1, 256}) {
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, 0, d, nchunks, 2, dq, out);
+            (void)hipEventRecord(e0);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, 0, d, nchunks, reps, dq, out);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            double pairs = (double)reps * B * nchunks * 4096;
+            printf("%-10s blocks=%3d: %.3f ms -> %.2f pairs/ns/CU = %.1f pairs/cycle/CU @2.4GHz ; %.0f cyc per 16-sample step of 4096 nodes\n", name, blocks, ms,
+                   pairs / (ms * 1e6), pairs / (ms * 1e6) / 2.4, ms * 1e6 * 2.4 / (reps * nchunks));
+        }
+    };
+    run(k<0>, "dot2");
+    run(k<1>, "mad24");
+    run(k<2>, "f32");
+    return 0;
+}
