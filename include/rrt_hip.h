@@ -97,7 +97,7 @@ int rrt_batch_elapsed_ms(rrt_batch *b, float *ms); /* HIP events around the last
 int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out);
 /* diagnostic builds (-DRRT_STAMPS): shader cycles wave 0 of query q spent in scan / barrier / nearest+line of sight /
  * choose parent / insert / go2goal; zeros in the product build */
-int rrt_batch_debug_cycles(rrt_batch *b, int32_t q, uint64_t out[6]);
+int rrt_batch_debug_cycles(rrt_batch *b, int32_t q, uint64_t out[38]); /* [0..5] phases, [6..37] per-wave owner-phase cycles */
 /* device-resident result slab of the batch: [vcost f64 | nodes u32 (x | y<<16) | parent i32], each [Q][stride],
  * stride = bytes / (16 Q)  (for the multi-GPU gather) */
 int rrt_batch_result_block(rrt_batch *b, void **dev_ptr, int64_t *bytes);

@@ -92,7 +92,7 @@ def lib():
             "rrt_batch_elapsed_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
             "rrt_batch_get_result": ([vp, i32, C.POINTER(Result)], C.c_int),
             "rrt_batch_result_block": ([vp, C.POINTER(vp), C.POINTER(i64)], C.c_int),
-            "rrt_batch_debug_cycles": ([vp, i32, C.POINTER(C.c_uint64 * 6)], C.c_int),
+            "rrt_batch_debug_cycles": ([vp, i32, C.POINTER(C.c_uint64 * 38)], C.c_int),
             "rrt_plan": ([vp, C.POINTER(Query), u32, C.POINTER(Result)], C.c_int),
             "rrt_plan_resume": ([vp, vp, i32, C.POINTER(Result)], C.c_int),
             "rrt_plan_batch": ([vp, i32, C.POINTER(Query), C.POINTER(Result)], C.c_int),
@@ -296,7 +296,7 @@ class Batch:
         return res
 
     def debug_cycles(self, q):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 38)()
         _check(self.ctx.handle, lib().rrt_batch_debug_cycles(self._h, int(q), C.byref(out)))
         return list(out)
 

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #ifdef RRT_STAMPS
     unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
+    unsigned long long wcyc_acc = 0, wcyc_los = 0;
 #endif
 
     const double xc0 = ((double)(D->xs[0] + D->xg[0])) / 2.0, xc1 = ((double)(D->xs[1] + D->xg[1])) / 2.0;
@@ -174,10 +175,11 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 
     // Snapshot near set of sample X: first entry in (cost, index) order with cost < bound and a free line of
     // sight.  One whole wave.  Returns (pc, pi) or (inf, NONE); nnear = |within| over nodes [0, j0).
-    // Pass 1 streams the cell records once and keeps the two cheapest entries; only when both are blocked does
-    // pass 2 stream again and park every remaining entry below the bound in this wave's HBM list, which is then
-    // consumed in key order without touching the cells again.
-    u32x4 *clist = reinterpret_cast<u32x4 *>(spill) + (size_t)wave * (size_t)(bv.spill_stride / (2 * NWAVE));  // {index, cost lo, cost hi, -}
+    // The cell records are streamed once.  Every entry whose vcost alone is below the bound is parked in this
+    // wave's HBM list {index, d2, vcost}; the two cheapest entries are found on the fly under a screen that
+    // tightens to the second cheapest so far.  Only when both are blocked is the parked list priced and consumed
+    // in key order (no second pass over the cells, unless the list overflowed: a radius far beyond the cell size).
+    u32x4 *clist = reinterpret_cast<u32x4 *>(spill) + (size_t)wave * (size_t)(bv.spill_stride / (2 * NWAVE));
     const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE));
     auto snapshot_parent = [&](uint32_t X, int j0, bool check_j0, double bound, double &pc, uint32_t &pi, uint32_t &nnear,
                                uint32_t &ntests, uint32_t &tcells) {
@@ -191,7 +193,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         const int ny = cy1 - cy0 + 1, ncr = (cx1 - cx0 + 1) * ny;
         // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
         auto screen_of = [](double c) -> float { return (float)c * (1.0f + 1.0e-6f) + 4.0e-3f; };
+        auto hi_of = [](double c) -> uint32_t { return (uint32_t)((unsigned long long)__double_as_longlong(c) >> 32); };
         const float boundf = screen_of(bound);
+        const uint32_t boundhi = hi_of(bound);  // vcost >= bound  <=>  its high word > boundhi or (== and ...): `<=` keeps a superset
         const float FINF = __uint_as_float(0x7f800000u);
         // the cells of the ball's bounding box: lane c (< ncr, first 64) holds cell c's fill count and record offset
         uint32_t tcnt = 0, toff = 0;
@@ -202,15 +206,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         }
         double lbc = -1.0;
         uint32_t lbi = 0;
-        for (int pass = 0;; ++pass) {
-            const bool collect = pass > 0;
+        for (;;) {
             Top2 tt;
             tt.init();
             float m1 = FINF, m2 = FINF;  // this lane's two cheapest verified entries, rounded up to f32
             uint32_t hits = 0, nlist = 0;
-            // pass 0 only needs the two cheapest entries: once two are known, everything above the second (in f32, with
-            // margin) is screened out before any f64 work.  T is wave-uniform.
-            float T = boundf;
+            float T = boundf;            // wave-uniform screen, tightens to the second cheapest so far
+            uint32_t Thi = hi_of((double)boundf);
             for (int c0 = 0; c0 < ncr; c0 += CG) {  // CG cells at a time: CG independent record loads in flight
                 uint32_t cnt[CG];
                 const u32x4 *rec[CG];
@@ -245,89 +247,98 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         const uint32_t d2 = dist2(rc[g].x, X);
                         const bool hit = d2 < r2 && (!check_j0 || rc[g].y < (uint32_t)j0);
                         hits += hit ? 1u : 0u;
-                        const double V = __longlong_as_double((long long)(((unsigned long long)rc[g].w << 32) | rc[g].z));
-                        const bool maybe = hit && ((float)V + __builtin_amdgcn_sqrtf((float)d2) < T);  // never rejects a true candidate
-                        if (__ballot(maybe) == 0) continue;
-                        bool cand = false;
-                        double cn = 0.0;
-                        if (maybe) {
-                            cn = V + sqrt_u24(d2);
-                            cand = cn < bound && !key_lt(cn, rc[g].y, lbc, lbi);  // rrt.py:518, strict
+                        // park everything whose vcost alone can be below the bound (the high word of a non-negative f64 is monotone)
+                        const bool park = hit && rc[g].w <= boundhi;
+                        const unsigned long long pm = __ballot(park);
+                        if (pm == 0) continue;
+                        if (park) {
+                            const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+                            if (pos < clist_cap) clist[pos] = u32x4{rc[g].y, d2, rc[g].z, rc[g].w};
                         }
-                        if (cand) {
-                            tt.fold(cn, rc[g].y);
-                            const float cu = screen_of(cn);
-                            if (cu < m1) {
-                                m2 = m1;
-                                m1 = cu;
-                            } else if (cu < m2) {
-                                m2 = cu;
+                        nlist += (uint32_t)__builtin_popcountll(pm);
+                        // screens, cheapest first; none rejects an entry that belongs to the two cheapest
+                        const bool pre = park && rc[g].w <= Thi;
+                        if (__ballot(pre) == 0) continue;
+                        const double V = __longlong_as_double((long long)(((unsigned long long)rc[g].w << 32) | rc[g].z));
+                        const bool maybe = pre && ((float)V + __builtin_amdgcn_sqrtf((float)d2) < T);
+                        if (__ballot(maybe) == 0) continue;
+                        if (maybe) {
+                            const double cn = V + sqrt_u24(d2);
+                            if (cn < bound && !key_lt(cn, rc[g].y, lbc, lbi)) {  // rrt.py:518, strict
+                                tt.fold(cn, rc[g].y);
+                                const float cu = screen_of(cn);
+                                if (cu < m1) {
+                                    m2 = m1;
+                                    m1 = cu;
+                                } else if (cu < m2) {
+                                    m2 = cu;
+                                }
                             }
                         }
                         dirty = true;
-                        if (collect) {
-                            const unsigned long long m = __ballot(cand);
-                            if (cand) {
-                                const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                                const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
-                                if (pos < clist_cap) clist[pos] = u32x4{rc[g].y, (uint32_t)cb, (uint32_t)(cb >> 32), 0u};
-                            }
-                            nlist += (uint32_t)__builtin_popcountll(m);
-                        }
                     }
-                    if (dirty && !collect) {  // tighten the screen to (an upper bound of) the wave's second cheapest so far
+                    if (dirty) {  // tighten the screen to (an upper bound of) the wave's second cheapest so far
                         const float w1 = wave_min_f32_nonneg(m1);
                         const float w2 = wave_min_f32_nonneg(m1 == w1 ? m2 : m1);
                         T = w2 < boundf ? w2 : boundf;
+                        Thi = hi_of((double)T);
                     }
                 }
             }
             nnear = wave_sum_u32(hits);
-            if (!collect || nlist > clist_cap) {  // (a list that overflowed -- a huge radius -- is unusable: keep streaming, two tests per pass)
-                tt.wave_reduce();
-                if (tt.i1 == NONE) return;
-                int cc = 0;
-                bool ok = los_wave(og, H, node_xy(tt.i1), X, lane, cc);  // rrt.py:519
-                ntests += 1;
-                tcells += (uint32_t)cc;
-                if (ok) {
-                    pc = tt.c1;
-                    pi = tt.i1;
-                    return;
-                }
-                if (tt.i2 == NONE) return;
-                ok = los_wave(og, H, node_xy(tt.i2), X, lane, cc);
-                ntests += 1;
-                tcells += (uint32_t)cc;
-                if (ok) {
-                    pc = tt.c2;
-                    pi = tt.i2;
-                    return;
-                }
-                lbc = tt.c2;
-                lbi = tt.i2 + 1;
-                continue;  // both blocked: collect the rest
+            tt.wave_reduce();
+            if (tt.i1 == NONE) return;
+            int cc = 0;
+            bool ok = los_wave(og, H, node_xy(tt.i1), X, lane, cc);  // rrt.py:519
+            ntests += 1;
+            tcells += (uint32_t)cc;
+            if (ok) {
+                pc = tt.c1;
+                pi = tt.i1;
+                return;
             }
-            // consume the parked entries in key order
-            const uint32_t have = nlist;
+            if (tt.i2 == NONE) return;
+            ok = los_wave(og, H, node_xy(tt.i2), X, lane, cc);
+            ntests += 1;
+            tcells += (uint32_t)cc;
+            if (ok) {
+                pc = tt.c2;
+                pi = tt.i2;
+                return;
+            }
+            lbc = tt.c2;
+            lbi = tt.i2 + 1;
+            if (nlist > clist_cap) continue;  // the list overflowed: stream the cells again above the new lower bound
+            // both blocked: price the parked entries once (in place: {index, -, cost}; +inf = out), then consume them in
+            // key order
+            for (uint32_t p = (uint32_t)lane; p < nlist; p += 64) {
+                const u32x4 e = clist[p];  // {index, d2, vcost}
+                const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                double cn = f64_inf();
+                if ((float)V + __builtin_amdgcn_sqrtf((float)e.y) < boundf) {
+                    const double c = V + sqrt_u24(e.y);
+                    if (c < bound && !key_lt(c, e.x, lbc, lbi)) cn = c;
+                }
+                const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
+                clist[p] = u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)};
+            }
             for (;;) {
                 double bc = f64_inf();
                 uint32_t bi = NONE;
-                for (uint32_t p = (uint32_t)lane; p < have; p += 64) {
+                for (uint32_t p = (uint32_t)lane; p < nlist; p += 64) {
                     const u32x4 e = clist[p];
-                    const double cn = __longlong_as_double((long long)(((unsigned long long)e.z << 32) | e.y));
-                    if (!key_lt(cn, e.x, lbc, lbi) && key_lt(cn, e.x, bc, bi)) {
+                    const double cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                    if (cn < bound && !key_lt(cn, e.x, lbc, lbi) && key_lt(cn, e.x, bc, bi)) {
                         bc = cn;
                         bi = e.x;
                     }
                 }
                 wave_min_f64_idx(bc, bi);
-                if (bi == NONE) break;
-                int cc = 0;
-                const bool ok = los_wave(og, H, node_xy(bi), X, lane, cc);
+                if (bi == NONE) return;  // every entry was tried
+                const bool ok2 = los_wave(og, H, node_xy(bi), X, lane, cc);
                 ntests += 1;
                 tcells += (uint32_t)cc;
-                if (ok) {
+                if (ok2) {
                     pc = bc;
                     pi = bi;
                     return;
@@ -335,7 +346,6 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 lbc = bc;
                 lbi = bi + 1;
             }
-            return;  // every remaining entry was tried
         }
     };
 
@@ -434,6 +444,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         STAMP(1);
 
         // ---------------- B: owner phase, wave k resolves sample k against the snapshot ----------------
+#ifdef RRT_STAMPS
+        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
         if (wave < nb) {
             const int k = wave;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);  // every wave holds the same xv
@@ -458,7 +471,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
             const double cnear_s = Vs + sqrt_u32(d2s);
+#ifdef RRT_STAMPS
+            const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+#endif
             if (star) snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);  // no block node is in the cells yet
+#ifdef RRT_STAMPS
+            wcyc_los += __builtin_amdgcn_s_memtime() - tl0;
+#endif
             if (lane == 0) {
                 BRec r;
                 r.d2s = d2s;
@@ -477,6 +496,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 brec[k] = r;
             }
         }
+#ifdef RRT_STAMPS
+        wcyc_acc += __builtin_amdgcn_s_memtime() - tb0;
+#endif
         STAMP(2);
         __syncthreads();
         STAMP(3);
@@ -806,6 +828,12 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         for (int k = 0; k < 6; ++k) D->cyc[k] = cyc[k];
 #endif
     }
+#ifdef RRT_STAMPS
+    if (lane == 0) {
+        D->wcyc[wave] = wcyc_acc;
+        D->wcyc[16 + wave] = wcyc_los;
+    }
+#endif
 }
 
 }  // namespace rrtdev

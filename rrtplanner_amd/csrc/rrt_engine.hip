@@ -243,6 +243,7 @@ static void arm_desc(QDesc &d) {
     d.ub_count = 0;
     d.sum_j = d.sum_cells_nn = d.sum_near = d.sum_cells_cand = d.n_los_cand = 0;
     for (auto &c : d.cyc) c = 0;
+    for (auto &c : d.wcyc) c = 0;
 }
 
 extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu) {
@@ -450,9 +451,10 @@ extern "C" int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out) {
     return d.status < 0 ? d.status : RRT_OK;
 }
 
-extern "C" int rrt_batch_debug_cycles(rrt_batch *b, int32_t q, uint64_t out[6]) {
+extern "C" int rrt_batch_debug_cycles(rrt_batch *b, int32_t q, uint64_t out[38]) {
     if (!b || !out || q < 0 || q >= b->Q) return fail(nullptr, RRT_E_ARG, "rrt_batch_debug_cycles: bad argument");
     for (int k = 0; k < 6; ++k) out[k] = b->h_desc[(size_t)q].cyc[k];
+    for (int k = 0; k < 32; ++k) out[6 + k] = b->h_desc[(size_t)q].wcyc[k];
     return RRT_OK;
 }
 

@@ -42,6 +42,7 @@ struct QDesc {
     int32_t status, i, j, nsoln, vbest_soln, vgoal, found, i_switch;
     double cmin_soln;
     unsigned long long sum_j, sum_cells_nn, sum_near, sum_cells_cand, n_los_cand;
+    unsigned long long wcyc[32]; // diagnostic build: per-wave cycles in the block kernel's owner phase [0..15] and its LoS part [16..31]
     unsigned long long cyc[6];  // diagnostic build (-DRRT_STAMPS): wave-0 cycles in scan / pre-barrier / barrier / B+C / D / go2goal
 };
 

@@ -36,6 +36,9 @@ cyc = b.debug_cycles(0)
 names = ["A scan+wave-reduce", "barrier 1", "B nearest+LoS+dup", "C choose parent", "D insert", "go2goal"]
 tot = sum(cyc) or 1
 print(f"kernel {ms:.2f} ms, n={a.n}, nodes={r.c.j}, iters/s={a.n/ms*1e3:.0f}, status={r.c.status}")
+w = cyc[6:]; cyc = cyc[:6]
+print("per-wave owner-phase cyc/iter:", [round(x / a.n) for x in w[:16]])
+print("per-wave near-set part cyc/iter:", [round(x / a.n) for x in w[16:]])
 for nm, c in zip(names, cyc):
     print(f"  {nm:22s} {c:14d} cyc  {100*c/tot:5.1f}%  {c/a.n:9.1f} cyc/iter")
 print(f"  total stamped cycles {tot} = {tot/a.n:.0f} cyc/iter ; los_cand={r.c.n_los_cand} near={r.c.sum_near}")
