@@ -744,53 +744,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     // ---------------- go2goal (rrt.py:311-332): same branch and bound as rrt_expand_kernel ----------------
     int vgoal = 0, found = 0;
     if (status == ST_RUNNING) {
-        double *costs = reinterpret_cast<double *>(spill);
-        for (int k = t; k < j; k += TPB) costs[k] = vcost[k] + sqrt_u32(dist2(nodes_g[k], xg));  // rrt.py:313-314
-        __syncthreads();
         status = ST_DONE;
-        double pc = f64_inf(), lbc = -1.0;
-        uint32_t pi = NONE, lbi = 0;
-        int round = 0;
-        for (;;) {
-            Top2 tt;
-            tt.init();
-            for (int k = t; k < j; k += TPB) {
-                const double cn = costs[k];
-                if (!key_lt(cn, (uint32_t)k, lbc, lbi) && key_lt(cn, (uint32_t)k, pc, pi)) tt.fold(cn, (uint32_t)k);
-            }
-            tt.wave_reduce();
-            BSlot bs;
-            bs.pc = f64_inf();
-            bs.pi = NONE;
-            bs.uc = tt.c2;
-            bs.ui = tt.i2;
-            bs.cells = bs.tested = 0;
-            if (tt.i1 != NONE) {
-                int cc = 0;
-                if (los_wave(og, H, nodes_g[tt.i1], xg, lane, cc)) {  // rrt.py:318
-                    bs.pc = tt.c1;
-                    bs.pi = tt.i1;
-                }
-                lbc = tt.c1;
-                lbi = tt.i1 + 1;
-            }
-            if (lane == 0) bslots[(round & 1) * NWAVE + wave] = bs;
-            __syncthreads();
-            BSlot rr;
-            rr.pc = rr.uc = f64_inf();
-            rr.pi = rr.ui = NONE;
-            if (lane < NWAVE) rr = bslots[(round & 1) * NWAVE + lane];
-            ++round;
-            double npc = rr.pc, uc = rr.uc;
-            uint32_t npi = rr.pi, ui = rr.ui;
-            wave_min_f64_idx(npc, npi);
-            wave_min_f64_idx(uc, ui);
-            if (key_lt(npc, npi, pc, pi)) {
-                pc = npc;
-                pi = npi;
-            }
-            if (ui == NONE || !key_lt(uc, ui, pc, pi)) break;
-        }
+        double pc;
+        uint32_t pi;
+        go2goal_phase(og, H, nodes_g, vcost, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)smem, bslots, t, lane, wave, pc, pi);
         if (pi != NONE) {
             found = 1;
             vgoal = j;  // rrt.py:319

@@ -165,6 +165,136 @@ struct BSlot {
     uint32_t cells, tested;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// go2goal (rrt.py:311-332): the goal connects to the first node, in stable (cost, index) order of
+// cost = vcost[k] + dist(k, goal), that has line of sight to it.  Nodes are counting-sorted into G2G_NB cost buckets
+// (LDS histogram, monotone bucket function), then tested in bucket order, 16 waves x G2G_U nodes per round; the
+// search ends once every node of the bucket that holds the cheapest passing node has been tested.
+constexpr int G2G_NB = 2048;  // cost buckets (2 x 8 KiB of LDS: fill cursors and bucket ends)
+constexpr int G2G_U = 4;      // nodes a wave tests per round
+
+__device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const uint32_t *nodes_g, const double *vcost, int j, uint32_t xg,
+                                              uint32_t *order, RRT_LDS uint32_t *lds16k, BSlot *bslots, int t, int lane, int wave,
+                                              double &pc, uint32_t &pi) {
+    RRT_LDS uint32_t *cursor = lds16k;          // [G2G_NB]
+    RRT_LDS uint32_t *bend = lds16k + G2G_NB;   // [G2G_NB]
+    auto cost_of = [&](int k) -> double { return vcost[k] + sqrt_u32(dist2(nodes_g[k], xg)); };  // rrt.py:313-314
+    // ---- cost range ----
+    double cmin = f64_inf(), cmax = 0.0;
+    for (int k = t; k < j; k += TPB) {
+        const double c = cost_of(k);
+        cmin = c < cmin ? c : cmin;
+        cmax = c > cmax ? c : cmax;
+    }
+    {
+        uint32_t dummy = 0;
+        wave_min_f64_idx(cmin, dummy);
+        double neg = -cmax;  // max via min on the order-reversed bit pattern is not available for negatives: use bits of cmax directly
+        (void)neg;
+        // max of non-negative doubles == max of their bit patterns; reduce as min of the complement
+        unsigned long long mb = ~(unsigned long long)__double_as_longlong(cmax);
+        uint32_t hi = (uint32_t)(mb >> 32), lo = (uint32_t)mb;
+        const uint32_t mh = wave_min_u32(hi);
+        const uint32_t ml = wave_min_u32(hi == mh ? lo : NONE);
+        cmax = __longlong_as_double((long long)~(((unsigned long long)mh << 32) | ml));
+        if (lane == 0) {
+            bslots[wave].pc = cmin;
+            bslots[wave].uc = cmax;
+        }
+        __syncthreads();
+        double a = f64_inf(), b = 0.0;
+        for (int w = 0; w < NWAVE; ++w) {
+            const double x = bslots[w].pc, y = bslots[w].uc;
+            a = x < a ? x : a;
+            b = y > b ? y : b;
+        }
+        cmin = a;
+        cmax = b;
+        __syncthreads();
+    }
+    const double scale = (cmax > cmin) ? (double)(G2G_NB - 1) / (cmax - cmin) : 0.0;
+    auto bucket_of = [&](double c) -> uint32_t {  // monotone non-decreasing in c
+        const double f = (c - cmin) * scale;
+        uint32_t b = (uint32_t)f;
+        return b > (uint32_t)(G2G_NB - 1) ? (uint32_t)(G2G_NB - 1) : b;
+    };
+    // ---- histogram, exclusive scan, scatter ----
+    for (int b = t; b < 2 * G2G_NB; b += TPB) lds16k[b] = 0;
+    __syncthreads();
+    for (int k = t; k < j; k += TPB) __hip_atomic_fetch_add(&cursor[bucket_of(cost_of(k))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    {
+        // thread t owns buckets 2t, 2t+1 (G2G_NB == 2 * TPB)
+        const uint32_t c0 = cursor[2 * t], c1 = cursor[2 * t + 1];
+        uint32_t incl = c0 + c1;
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
+        if (lane == 63) bslots[wave].pi = incl;  // wave total
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += bslots[w].pi;
+        const uint32_t ex = base + incl - (c0 + c1);
+        cursor[2 * t] = ex;
+        bend[2 * t] = ex + c0;
+        cursor[2 * t + 1] = ex + c0;
+        bend[2 * t + 1] = ex + c0 + c1;
+        __syncthreads();
+    }
+    for (int k = t; k < j; k += TPB) {
+        const uint32_t pos = __hip_atomic_fetch_add(&cursor[bucket_of(cost_of(k))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        order[pos] = (uint32_t)k;
+    }
+    __syncthreads();
+    // ---- test in bucket order ----
+    pc = f64_inf();
+    pi = NONE;
+    uint32_t limit = (uint32_t)j;
+    int round = 0;
+    for (uint32_t pos0 = 0; pos0 < limit; pos0 += NWAVE * G2G_U) {
+        double bc = f64_inf();
+        uint32_t bi = NONE;
+#pragma unroll
+        for (int u = 0; u < G2G_U; ++u) {
+            const uint32_t p = pos0 + (uint32_t)(u * NWAVE + wave);
+            if (p < limit) {
+                const uint32_t k = order[p];
+                int cc = 0;
+                if (los_wave(og, H, nodes_g[k], xg, lane, cc)) {  // rrt.py:318
+                    const double c = cost_of((int)k);
+                    if (key_lt(c, k, bc, bi)) {
+                        bc = c;
+                        bi = k;
+                    }
+                }
+            }
+        }
+        BSlot *sl = bslots + (round & 1) * NWAVE;
+        if (lane == 0) {
+            sl[wave].pc = bc;
+            sl[wave].pi = bi;
+        }
+        __syncthreads();
+        double rc = f64_inf();
+        uint32_t ri = NONE;
+        if (lane < NWAVE) {
+            rc = sl[lane].pc;
+            ri = sl[lane].pi;
+        }
+        wave_min_f64_idx(rc, ri);
+        ++round;
+        if (key_lt(rc, ri, pc, pi)) {
+            pc = rc;
+            pi = ri;
+            const uint32_t e = bend[bucket_of(pc)];  // every node that could sort before it lies before this position
+            limit = e < limit ? e : limit;
+        }
+    }
+}
+
 #ifdef RRT_STAMPS
 #define STAMP(k)                                                \
     do {                                                        \
@@ -555,53 +685,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
     // untested one.
     int vgoal = 0, found = 0;
     if (status == ST_RUNNING) {
-        double *costs = reinterpret_cast<double *>(spill);
-        for (int k = t; k < j; k += TPB) costs[k] = vcost[k] + sqrt_u32(dist2(nodes_g[k], xg));  // rrt.py:313-314
-        __syncthreads();
         status = ST_DONE;
-        double pc = f64_inf(), lbc = -1.0;
-        uint32_t pi = NONE, lbi = 0;
-        int round = 0;
-        for (;;) {
-            Top2 tt;
-            tt.init();
-            for (int k = t; k < j; k += TPB) {
-                const double cn = costs[k];
-                if (!key_lt(cn, (uint32_t)k, lbc, lbi) && key_lt(cn, (uint32_t)k, pc, pi)) tt.fold(cn, (uint32_t)k);
-            }
-            tt.wave_reduce();
-            BSlot bs;
-            bs.pc = f64_inf();
-            bs.pi = NONE;
-            bs.uc = tt.c2;
-            bs.ui = tt.i2;
-            bs.cells = bs.tested = 0;
-            if (tt.i1 != NONE) {
-                int cc = 0;
-                if (los_wave(og, H, nodes_g[tt.i1], xg, lane, cc)) {  // rrt.py:318
-                    bs.pc = tt.c1;
-                    bs.pi = tt.i1;
-                }
-                lbc = tt.c1;
-                lbi = tt.i1 + 1;
-            }
-            if (lane == 0) bslots[(round & 1) * NWAVE + wave] = bs;
-            __syncthreads();
-            BSlot r;
-            r.pc = r.uc = f64_inf();
-            r.pi = r.ui = NONE;
-            if (lane < NWAVE) r = bslots[(round & 1) * NWAVE + lane];
-            ++round;
-            double npc = r.pc, uc = r.uc;
-            uint32_t npi = r.pi, ui = r.ui;
-            wave_min_f64_idx(npc, npi);
-            wave_min_f64_idx(uc, ui);
-            if (key_lt(npc, npi, pc, pi)) {
-                pc = npc;
-                pi = npi;
-            }
-            if (ui == NONE || !key_lt(uc, ui, pc, pi)) break;
-        }
+        double pc;
+        uint32_t pi;
+        go2goal_phase(og, H, nodes_g, vcost, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)smem, bslots, t, lane, wave, pc, pi);
         if (pi != NONE) {
             found = 1;
             vgoal = j;  // rrt.py:319
