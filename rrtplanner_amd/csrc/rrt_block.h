@@ -147,8 +147,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     double cmin_soln = D->cmin_soln;
     int i_switch = D->i_switch;
     int status = ST_RUNNING;
-    // statistics: per-lane accumulators of wave 0, folded once at the end
-    unsigned long long a_sum_j = 0, a_cells_nn = 0, a_near = 0, a_cells_cand = 0, a_los_cand = 0;
+    // statistics: per-lane accumulators of wave 0 in LDS (statred), folded once at the end
 #ifdef RRT_STAMPS
     unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
@@ -167,6 +166,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         const uint32_t n0 = nodes_g[0];
         for (int k = t; k < lds_nodes; k += TPB) nodes_lds[k] = (k < j) ? nodes_g[k] : n0;
         for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
+        if (t < BS * 5) statred[t] = 0;
     }
     __syncthreads();
 
@@ -236,11 +236,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 for (uint32_t s0 = 0; s0 < maxc; s0 += 64) {
                     const uint32_t s = s0 + (uint32_t)lane;
                     u32x4 rc[CG];
+                    // unconditional loads (a clamped slot of the same cell; every cell array has at least one slot) so that
+                    // all CG loads are issued back to back; lanes past the fill count get a far-away point afterwards
 #pragma unroll
-                    for (int g = 0; g < CG; ++g) {
-                        rc[g] = u32x4{0x7fff7fffu, NONE, 0u, 0u};  // far away: never within the radius
-                        if (s < cnt[g]) rc[g] = rec[g][s];            // {xy, index, vcost}
-                    }
+                    for (int g = 0; g < CG; ++g) rc[g] = rec[g][s < cnt[g] ? s : 0u];  // {xy, index, vcost}
+#pragma unroll
+                    for (int g = 0; g < CG; ++g)
+                        if (!(s < cnt[g])) rc[g].x = 0x7fff7fffu;  // never within the radius
                     bool dirty = false;
 #pragma unroll
                     for (int g = 0; g < CG; ++g) {
@@ -288,20 +290,21 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             nnear = wave_sum_u32(hits);
             tt.wave_reduce();
             if (tt.i1 == NONE) return;
-            int cc = 0;
-            bool ok = los_wave(og, H, node_xy(tt.i1), X, lane, cc);  // rrt.py:519
+            // the two cheapest, both lines of sight in flight together (rrt.py:519); the second counts only if needed
+            bool ok1, ok2;
+            int cc1, cc2;
+            los_wave2(og, H, node_xy(tt.i1), tt.i2 != NONE ? node_xy(tt.i2) : X, tt.i2 != NONE, X, lane, ok1, cc1, ok2, cc2);
             ntests += 1;
-            tcells += (uint32_t)cc;
-            if (ok) {
+            tcells += (uint32_t)cc1;
+            if (ok1) {
                 pc = tt.c1;
                 pi = tt.i1;
                 return;
             }
             if (tt.i2 == NONE) return;
-            ok = los_wave(og, H, node_xy(tt.i2), X, lane, cc);
             ntests += 1;
-            tcells += (uint32_t)cc;
-            if (ok) {
+            tcells += (uint32_t)cc2;
+            if (ok2) {
                 pc = tt.c2;
                 pi = tt.i2;
                 return;
@@ -309,8 +312,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             lbc = tt.c2;
             lbi = tt.i2 + 1;
             if (nlist > clist_cap) continue;  // the list overflowed: stream the cells again above the new lower bound
-            // both blocked: price the parked entries once (in place: {index, -, cost}; +inf = out), then consume them in
-            // key order
+            // both blocked: price the parked entries once (in place: {index, -, cost}; +inf = out), then consume them
+            // two at a time in key order
             for (uint32_t p = (uint32_t)lane; p < nlist; p += 64) {
                 const u32x4 e = clist[p];  // {index, d2, vcost}
                 const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
@@ -323,28 +326,33 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 clist[p] = u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)};
             }
             for (;;) {
-                double bc = f64_inf();
-                uint32_t bi = NONE;
+                Top2 t2;
+                t2.init();
                 for (uint32_t p = (uint32_t)lane; p < nlist; p += 64) {
                     const u32x4 e = clist[p];
                     const double cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
-                    if (cn < bound && !key_lt(cn, e.x, lbc, lbi) && key_lt(cn, e.x, bc, bi)) {
-                        bc = cn;
-                        bi = e.x;
-                    }
+                    if (cn < bound && !key_lt(cn, e.x, lbc, lbi)) t2.fold(cn, e.x);
                 }
-                wave_min_f64_idx(bc, bi);
-                if (bi == NONE) return;  // every entry was tried
-                const bool ok2 = los_wave(og, H, node_xy(bi), X, lane, cc);
+                t2.wave_reduce();
+                if (t2.i1 == NONE) return;  // every entry was tried
+                los_wave2(og, H, node_xy(t2.i1), t2.i2 != NONE ? node_xy(t2.i2) : X, t2.i2 != NONE, X, lane, ok1, cc1, ok2, cc2);
                 ntests += 1;
-                tcells += (uint32_t)cc;
-                if (ok2) {
-                    pc = bc;
-                    pi = bi;
+                tcells += (uint32_t)cc1;
+                if (ok1) {
+                    pc = t2.c1;
+                    pi = t2.i1;
                     return;
                 }
-                lbc = bc;
-                lbi = bi + 1;
+                if (t2.i2 == NONE) return;
+                ntests += 1;
+                tcells += (uint32_t)cc2;
+                if (ok2) {
+                    pc = t2.c2;
+                    pi = t2.i2;
+                    return;
+                }
+                lbc = t2.c2;
+                lbi = t2.i2 + 1;
             }
         }
     };
@@ -535,8 +543,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     const bool myacc = inr && acc0;
                     const int jmine = j + __builtin_popcount(racc & ltmask);  // j as this sample sees it
                     if (inr) {
-                        a_sum_j += (unsigned long long)jmine;
-                        a_cells_nn += (unsigned long long)(r.los_s & 0x7fffffffu);
+                        statred[lane * 5 + 0] += (unsigned long long)jmine;
+                        statred[lane * 5 + 1] += (unsigned long long)(r.los_s & 0x7fffffffu);
                         if (logs) {
                             const size_t o = (size_t)q * bv.n_cap + i0 + lane;
                             bv.nearest_log[o] = (int32_t)r.vs;
@@ -547,9 +555,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     }
                     if (myacc) {
                         if (star) {
-                            a_near += r.nnear;
-                            a_los_cand += r.pstat >> 20;
-                            a_cells_cand += r.pstat & 0xfffffu;
+                            statred[lane * 5 + 2] += r.nnear;
+                            statred[lane * 5 + 4] += r.pstat >> 20;
+                            statred[lane * 5 + 3] += r.pstat & 0xfffffu;
                         }
                         const uint32_t cellbit = (uint32_t)ux(xv) * (uint32_t)H + (uint32_t)uy(xv);
                         nodes_g[jmine] = xv;
@@ -656,8 +664,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         }
                     }
                     if (lane == 0) {
-                        a_sum_j += (unsigned long long)j;
-                        a_cells_nn += (unsigned long long)cells;
+                        statred[0] += (unsigned long long)j;
+                        statred[1] += (unsigned long long)cells;
                         if (logs) {
                             const size_t o = (size_t)q * bv.n_cap + i0 + k;
                             bv.nearest_log[o] = (int32_t)vn;
@@ -669,9 +677,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     if (acc) {
                         if (lane == 0) {
                             if (star) {
-                                a_near += nnear;
-                                a_los_cand += ntests;
-                                a_cells_cand += tcells;
+                                statred[2] += nnear;
+                                statred[4] += ntests;
+                                statred[3] += tcells;
                             }
                             nodes_g[j] = Xk;
                             if (j < lds_nodes) nodes_lds[j] = Xk;
@@ -732,13 +740,6 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 
     // cell fill counts back to HBM (a resumed launch reloads them); fold wave 0's statistics
     for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
-    if (wave == 0 && lane < BS) {
-        statred[lane * 5 + 0] = a_sum_j;
-        statred[lane * 5 + 1] = a_cells_nn;
-        statred[lane * 5 + 2] = a_near;
-        statred[lane * 5 + 3] = a_cells_cand;
-        statred[lane * 5 + 4] = a_los_cand;
-    }
     __syncthreads();
 
     // ---------------- go2goal (rrt.py:311-332): same branch and bound as rrt_expand_kernel ----------------

@@ -138,4 +138,37 @@ __device__ __forceinline__ bool los_wave(const uint8_t *__restrict__ og, int H, 
     return true;
 }
 
+// Two lines of sight a0 -> b and a1 -> b at once (the second only if `has1`): for segments shorter than 64 cells both
+// cell loads are in flight together, so a failed first test does not cost a second memory round trip.
+__device__ __forceinline__ void los_wave2(const uint8_t *__restrict__ og, int H, uint32_t a0, uint32_t a1, bool has1, uint32_t b, int lane,
+                                          bool &ok0, int &cells0, bool &ok1, int &cells1) {
+    const rrt_line_t l0 = rrt_line_setup(ux(a0), uy(a0), ux(b), uy(b));
+    const rrt_line_t l1 = rrt_line_setup(ux(a1), uy(a1), ux(b), uy(b));
+    ok1 = false;
+    cells1 = 0;
+    if (l0.major < 64 && (!has1 || l1.major < 64)) {
+        uint8_t v0 = 0, v1 = 0;
+        if (lane <= l0.major) {
+            int x, y;
+            rrt_line_cell(&l0, lane, &x, &y);
+            v0 = og[(size_t)x * H + y];
+        }
+        if (has1 && lane <= l1.major) {
+            int x, y;
+            rrt_line_cell(&l1, lane, &x, &y);
+            v1 = og[(size_t)x * H + y];
+        }
+        const unsigned long long m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
+        ok0 = m0 == 0;
+        cells0 = m0 ? (int)__builtin_ctzll(m0) + 1 : l0.major + 1;
+        if (has1) {
+            ok1 = m1 == 0;
+            cells1 = m1 ? (int)__builtin_ctzll(m1) + 1 : l1.major + 1;
+        }
+        return;
+    }
+    ok0 = los_wave(og, H, a0, b, lane, cells0);
+    if (has1) ok1 = los_wave(og, H, a1, b, lane, cells1);
+}
+
 }  // namespace rrtdev
