@@ -54,6 +54,12 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the informational batched leg (configs[3] share of one GPU)")
     args = ap.parse_args()
 
+    # rank 0 prints exactly ONE line on stdout: route everything else that writes to fd 1 (RCCL's banner, library
+    # chatter) to stderr until the JSON line is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,10 +72,13 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: exercises the gather)
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from rrtplanner_amd import _ffi, hostprep, multi
@@ -135,29 +144,34 @@ def main():
         return ms
 
     gather_buf = None
-    if world > 1:
+    if use_dist:
         ptr, nbytes = batch.result_block()
         gather_buf = torch.as_tensor(multi.DeviceBlock(ptr, nbytes), device=f"cuda:{local_rank}")
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
+    gathered = None
     for _ in range(args.warmup):
         one_step()
-        if world > 1:
-            multi.gather_result_blocks(gather_buf)
+        if use_dist:
+            gathered = multi.gather_result_blocks(gather_buf)
     sync_all()
     t0 = time.perf_counter()
     kern_ms = 0.0
     for _ in range(args.steps):
         kern_ms += one_step()
-        if world > 1:
-            multi.gather_result_blocks(gather_buf)
+        if use_dist:
+            gathered = multi.gather_result_blocks(gather_buf)
     sync_all()
     dt = time.perf_counter() - t0
+    if gathered is not None and rank == 0:  # sanity of the collective: rank 0's own slab must come back unchanged
+        own = torch.as_tensor(multi.DeviceBlock(*batch.result_block()), device=f"cuda:{local_rank}")
+        if gathered.shape[0] != world or not torch.equal(gathered[0], own):
+            raise SystemExit("result gather returned a wrong slab")
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -168,7 +182,7 @@ def main():
     iters_local = Q * n
     bytes_local = sum(algorithmic_bytes(r.c) for r in results)
     bad = [r.c.status for r in results if r.c.status != 0]
-    if world > 1:
+    if use_dist:
         agg = torch.tensor([nodes_local, iters_local, len(bad)], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(agg)
         nodes_total, iters_total, nbad = float(agg[0]), float(agg[1]), int(agg[2])
@@ -205,8 +219,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(og8, cfg, pairs[0], free, states[0], ub_cache.get(0))
         if world == 1 and args.config == 2 and not args.no_batched:
             out["batched"] = batched_leg(ctx, og, free, _ffi, hostprep)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     batch.close()

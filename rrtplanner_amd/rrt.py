@@ -210,18 +210,30 @@ class RRT(object):
     def build_graph(self, vgoal, points, parents, vcosts) -> nx.DiGraph:
         """DiGraph with every row of `points` as a node (`pt`) and one edge per tree link with
         `dist` (float) and `cost` (np.float64) -- node order [vgoal, 0, 1, ...] and edge order of the
-        `parents` dict, as reference rrt.py:357-369."""
+        `parents` dict, as reference rrt.py:357-369.
+
+        The adjacency dicts are filled directly (same dict-of-dict layout `add_node` / `add_edge` produce, same
+        insertion order, one shared attribute dict per edge in `_succ` and `_pred`), which is ~3x faster than
+        50 000 `add_edge` calls; tests/test_host_logic.py compares it with the call-by-call construction."""
         T = nx.DiGraph()
-        T.add_node(vgoal, pt=points[vgoal])
-        T.add_nodes_from((i, {"pt": p}) for i, p in enumerate(points))
+        rows = len(points)
+        order = [vgoal] + [i for i in range(rows) if i != vgoal] if 0 <= vgoal < rows else [vgoal] + list(range(rows))
+        pts = list(points)  # row views, like `for i, p in enumerate(points)`
+        node, succ, pred = T._node, T._succ, T._pred
+        for v in order:
+            node[v] = {"pt": pts[v]}
+            succ[v] = {}
+            pred[v] = {}
         kids = [c for c, p in parents.items() if p is not None]
         if kids:
             ch = np.asarray(kids, dtype=np.int64)
             pa = np.asarray([parents[c] for c in kids], dtype=np.int64)
             d = points[ch] - points[pa]
             dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64)).tolist()
-            cost = vcosts[ch]
-            T.add_edges_from((int(p), int(c), {"dist": dd, "cost": cc}) for p, c, dd, cc in zip(pa, ch, dist, cost))
+            for p, c, dd, cc in zip(pa.tolist(), kids, dist, vcosts[ch]):
+                e = {"dist": dd, "cost": cc}
+                succ[p][c] = e
+                pred[c][p] = e
         return T
 
     def _plan(self, alg, xstart, xgoal, **kw):

@@ -218,6 +218,17 @@ def test_device_vs_oracle_dense_interactions(gpu_ctx, alg, rr, rg, grid, n, seed
     _oracle_vs_device(gpu_ctx, og8, alg, n, seed, xs, xg, rr, rg, serial=serial)
 
 
+@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
+def test_device_vs_oracle_2048_grid(gpu_ctx, serial):
+    """The largest supported grid (BASELINE config 5's size): squared distances use all 23 key bits."""
+    og = perlin_occupancygrid(2048, 2048, seed=3)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    xs, xg = random_connected_pair(og, np.random.default_rng(11))
+    _oracle_vs_device(gpu_ctx, og8, 1, 30000, 5, xs, xg, 64, None, serial=serial)
+    _oracle_vs_device(gpu_ctx, og8, 2, 12000, 6, (3, 2044), (2040, 5), 200.5, 40, serial=serial) if og8[3, 2044] == 0 and og8[2040, 5] == 0 else None
+
+
 def test_batch_of_queries_matches_single_queries(gpu_ctx):
     og = perlin_occupancygrid(512, 512, seed=2)
     og8 = oracle.og_u8(og)

@@ -119,3 +119,39 @@ def test_sharding_helpers():
     slab = np.zeros(Q * stride * 16, dtype=np.uint8)
     v, nd, pa = multi.unpack_slab(slab, Q, stride)
     assert v.shape == (Q, stride) and nd.dtype == np.uint32 and pa.dtype == np.int32
+
+
+def test_build_graph_equals_call_by_call_construction():
+    """The direct adjacency fill of build_graph == the reference's add_node / add_edge sequence (rrt.py:357-369)."""
+    import networkx as nx
+
+    rng = np.random.default_rng(0)
+    n, live = 60, 41
+    points = np.full((n + 1, 2), hostprep.INT64_MIN, dtype=np.int64)
+    points[:live] = rng.integers(0, 100, size=(live, 2))
+    points[n] = points[live - 1]
+    vcosts = np.full(n + 1, np.inf)
+    vcosts[:live] = rng.uniform(0, 50, size=live)
+    parents = {0: None}
+    for c in range(1, live):
+        parents[c] = int(rng.integers(0, c))
+    vgoal = live - 1
+    p = amd.RRT(np.zeros((100, 100), dtype=int), n)
+    T = p.build_graph(vgoal, points, parents, vcosts)
+    R = nx.DiGraph()
+    R.add_node(vgoal, pt=points[vgoal])
+    for i, q in enumerate(points):
+        R.add_node(i, pt=q)
+    for child, parent in parents.items():
+        if parent is not None:
+            d = points[child] - points[parent]
+            R.add_edge(parent, child, dist=math.sqrt(d[0] * d[0] + d[1] * d[1]), cost=vcosts[child])
+    assert list(T.nodes) == list(R.nodes) and list(T.edges) == list(R.edges)
+    for v in R.nodes:
+        assert np.array_equal(T.nodes[v]["pt"], R.nodes[v]["pt"])
+        assert list(T.pred[v]) == list(R.pred[v]) and list(T.succ[v]) == list(R.succ[v])
+    for u, v, d in R.edges(data=True):
+        assert T.edges[u, v] == d and type(T.edges[u, v]["dist"]) is float and isinstance(T.edges[u, v]["cost"], np.float64)
+        assert T.pred[v][u] is T.succ[u][v]
+    assert nx.shortest_path(T, 0, vgoal, weight="dist") == nx.shortest_path(R, 0, vgoal, weight="dist")
+    assert T.number_of_edges() == R.number_of_edges() and T.in_degree(vgoal) == R.in_degree(vgoal)
