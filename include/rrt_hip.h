@@ -84,6 +84,16 @@ const char *rrt_last_error_string(rrt_ctx *ctx); /* ctx may be NULL */
 /* RRT.__init__ / set_og (rrt.py:64-65, :261-272): og_nonzero is (W,H) C-order, 1 = obstacle. */
 int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, int32_t H);
 
+/* Device-resident noise grids (counterpart of oggen.perlin_occupancygrid, oggen.py:7-45: fractal gradient noise, min-max
+ * normalised over all frames, obstacle where value < thresh).  `octaves` lattices of unit gradients (host-drawn, seeded):
+ * octave o has dims[3*o..3*o+2] = (nz, nx, ny) lattice points, cell edge cells[o] pixels and amplitude amps[o]; grads holds
+ * the lattices back to back, 3 doubles per point.  All `frames` grids stay in HBM; frame 0 becomes the active grid.
+ * og_out (optional, host, frames*W*H bytes) receives a copy (the host needs it for free = argwhere(og == 0)). */
+int rrt_noise_grids(rrt_ctx *ctx, int32_t W, int32_t H, int32_t frames, float thresh, int32_t octaves, const int32_t *dims,
+                    const double *cells, const double *amps, const double *grads, uint8_t *og_out);
+/* make frame k of the resident noise grids the active grid (no upload; anim.py:92-93 style replanning) */
+int rrt_select_frame(rrt_ctx *ctx, int32_t frame);
+
 /* ---- resident batches: Q independent queries on the ctx's grid ------------------------- */
 int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t flags, rrt_batch **out);
 int rrt_batch_destroy(rrt_batch *b);

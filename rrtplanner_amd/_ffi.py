@@ -27,7 +27,7 @@ FLAG_SERIAL = 2
 
 # every symbol include/rrt_hip.h declares (tests/test_capi_symbols.py checks the library exports them)
 SYMBOLS = (
-    "rrt_ctx_create", "rrt_ctx_destroy", "rrt_last_error_string", "rrt_set_grid",
+    "rrt_ctx_create", "rrt_ctx_destroy", "rrt_last_error_string", "rrt_set_grid", "rrt_noise_grids", "rrt_select_frame",
     "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
     "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
@@ -82,6 +82,8 @@ def lib():
             "rrt_ctx_destroy": ([vp], C.c_int),
             "rrt_last_error_string": ([vp], C.c_char_p),
             "rrt_set_grid": ([vp, vp, i32, i32], C.c_int),
+            "rrt_noise_grids": ([vp, i32, i32, i32, C.c_float, i32, vp, vp, vp, vp, vp], C.c_int),
+            "rrt_select_frame": ([vp, i32], C.c_int),
             "rrt_batch_create": ([vp, i32, i32, u32, C.POINTER(vp)], C.c_int),
             "rrt_batch_destroy": ([vp], C.c_int),
             "rrt_batch_set_query": ([vp, i32, C.POINTER(Query)], C.c_int),
@@ -190,6 +192,21 @@ class Context:
             raise ValueError("occupancy grid must be 2-D")
         _check(self._h, lib().rrt_set_grid(self._h, g.ctypes.data, g.shape[0], g.shape[1]))
         self.shape = g.shape
+
+    def noise_grids(self, W, H, frames, thresh, dims, cells, amps, grads):
+        """Generate `frames` noise grids on the device; returns the host copy (frames, W, H) uint8."""
+        dims = np.ascontiguousarray(dims, dtype=np.int32).reshape(-1, 3)
+        cells = np.ascontiguousarray(cells, dtype=np.float64)
+        amps = np.ascontiguousarray(amps, dtype=np.float64)
+        grads = np.ascontiguousarray(grads, dtype=np.float64)
+        out = np.zeros((frames, W, H), dtype=np.uint8)
+        _check(self._h, lib().rrt_noise_grids(self._h, int(W), int(H), int(frames), float(thresh), dims.shape[0], dims.ctypes.data,
+                                              cells.ctypes.data, amps.ctypes.data, grads.ctypes.data, out.ctypes.data))
+        self.shape = (W, H)
+        return out
+
+    def select_frame(self, k):
+        _check(self._h, lib().rrt_select_frame(self._h, int(k)))
 
     # ---- one-shot ----
     def plan(self, query, n, logs=False, serial=False):

@@ -22,7 +22,10 @@ static thread_local std::string g_last_error;
 struct rrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    uint8_t *og = nullptr;  // device (W,H)
+    uint8_t *og = nullptr;      // active grid, device (W,H): og_buf + frame * W * H
+    uint8_t *og_buf = nullptr;  // allocation holding 1 uploaded grid or `nframes` generated grids
+    size_t og_buf_bytes = 0;
+    int32_t nframes = 1;
     int32_t W = 0, H = 0;
     std::string err;
     rrt_batch *single = nullptr;  // batch behind rrt_plan / rrt_plan_resume
@@ -93,7 +96,7 @@ extern "C" int rrt_ctx_destroy(rrt_ctx *ctx) {
     if (!ctx) return RRT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->single) rrt_batch_destroy(ctx->single);
-    if (ctx->og) (void)hipFree(ctx->og);
+    if (ctx->og_buf) (void)hipFree(ctx->og_buf);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RRT_OK;
@@ -105,15 +108,148 @@ extern "C" int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, 
         return fail(ctx, RRT_E_UNSUPPORTED, "rrt_set_grid: %dx%d exceeds the 2048x2048 packed-key path", W, H);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->og && (size_t)ctx->W * ctx->H != (size_t)W * H) {
-        HIPCHK(ctx, hipFree(ctx->og));
-        ctx->og = nullptr;
+    if (ctx->og_buf && ctx->og_buf_bytes != (size_t)W * H) {
+        HIPCHK(ctx, hipFree(ctx->og_buf));
+        ctx->og_buf = nullptr;
     }
-    if (!ctx->og) HIPCHK(ctx, hipMalloc(&ctx->og, (size_t)W * H));
+    if (!ctx->og_buf) {
+        HIPCHK(ctx, hipMalloc(&ctx->og_buf, (size_t)W * H));
+        ctx->og_buf_bytes = (size_t)W * H;
+    }
+    ctx->og = ctx->og_buf;
+    ctx->nframes = 1;
     HIPCHK(ctx, hipMemcpyAsync(ctx->og, og_nonzero, (size_t)W * H, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->W = W;
     ctx->H = H;
+    return RRT_OK;
+}
+
+// ---- device-resident noise grids (counterpart of oggen.perlin_occupancygrid, oggen.py:7-45) ----
+namespace {
+__device__ __forceinline__ double fade5(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+__device__ __forceinline__ uint32_t f32_order(float v) {  // monotone map float -> uint
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unorder(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// value[f][x][y] = float32(sum over octaves amp * gradient_noise(f/cell, x/cell, y/cell)), evaluated in f64 in exactly the
+// order of rrtplanner_amd/oggen.py (_gradient_noise3 / noise_field); running min / max of the float32 values.
+__global__ void noise_eval_kernel(int W, int H, int F, int octaves, const int32_t *dims, const double *cells, const double *amps,
+                                  const double *grads, float *val, uint32_t *minmax) {
+    const size_t total = (size_t)F * W * H;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(p % H), x = (int)((p / H) % W), f = (int)(p / ((size_t)H * W));
+        double acc = 0.0;
+        size_t goff = 0;
+        for (int o = 0; o < octaves; ++o) {
+            const int nz = dims[3 * o], nx = dims[3 * o + 1], ny = dims[3 * o + 2];
+            const double cell = cells[o];
+            const double z = (double)f / cell, xx = (double)x / cell, yy = (double)y / cell;
+            const double z0 = floor(z), x0 = floor(xx), y0 = floor(yy);
+            const double fz = z - z0, fx = xx - x0, fy = yy - y0;
+            const double uz = fade5(fz), ux = fade5(fx), uy = fade5(fy);
+            const double *g = grads + goff;
+            double out = 0.0;
+            for (int dz = 0; dz < 2; ++dz) {
+                const double wz = dz ? uz : 1.0 - uz;
+                for (int dx = 0; dx < 2; ++dx) {
+                    const double wx = dx ? ux : 1.0 - ux;
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const double wy = dy ? uy : 1.0 - uy;
+                        const double *gg = g + 3 * ((((size_t)((int)z0 + dz)) * nx + ((int)x0 + dx)) * ny + ((int)y0 + dy));
+                        const double dot = gg[0] * (fz - (double)dz) + gg[1] * (fx - (double)dx) + gg[2] * (fy - (double)dy);
+                        out = out + wz * wx * wy * dot;
+                    }
+                }
+            }
+            acc = acc + amps[o] * out;
+            goff += (size_t)nz * nx * ny * 3;
+        }
+        const float v = (float)acc;
+        val[p] = v;
+        const uint32_t k = f32_order(v);
+        lo = k < lo ? k : lo;
+        hi = k > hi ? k : hi;
+    }
+    atomicMin(&minmax[0], lo);
+    atomicMax(&minmax[1], hi);
+}
+
+// xynoise -= min ; xynoise /= (max - min) ; og = where(xynoise >= thresh, 0, 1)   (oggen.py:40-44, float32 arithmetic)
+__global__ void noise_thresh_kernel(size_t total, const float *val, const uint32_t *minmax, float thresh, uint8_t *og) {
+    const float mn = f32_unorder(minmax[0]), mx = f32_unorder(minmax[1]);
+    const float den = mx - mn;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const float n = (val[p] - mn) / den;
+        og[p] = (n >= thresh) ? (uint8_t)0 : (uint8_t)1;
+    }
+}
+}  // namespace
+
+extern "C" int rrt_noise_grids(rrt_ctx *ctx, int32_t W, int32_t H, int32_t frames, float thresh, int32_t octaves, const int32_t *dims,
+                               const double *cells, const double *amps, const double *grads, uint8_t *og_out) {
+    if (!ctx || W < 1 || H < 1 || frames < 1 || octaves < 1 || !dims || !cells || !amps || !grads)
+        return fail(ctx, RRT_E_ARG, "rrt_noise_grids: bad argument");
+    if (W > 2048 || H > 2048) return fail(ctx, RRT_E_UNSUPPORTED, "rrt_noise_grids: %dx%d exceeds 2048x2048", W, H);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t total = (size_t)frames * W * H;
+    size_t ngrad = 0;
+    for (int o = 0; o < octaves; ++o) {
+        const int nz = dims[3 * o], nx = dims[3 * o + 1], ny = dims[3 * o + 2];
+        if (nz < 2 || nx < 2 || ny < 2 || !(cells[o] > 0.0) || std::floor((frames - 1) / cells[o]) + 2 > nz ||
+            std::floor((W - 1) / cells[o]) + 2 > nx || std::floor((H - 1) / cells[o]) + 2 > ny)
+            return fail(ctx, RRT_E_ARG, "rrt_noise_grids: lattice %d does not cover the field", o);
+        ngrad += (size_t)nz * nx * ny * 3;
+    }
+    if (ctx->og_buf && ctx->og_buf_bytes != total) {
+        HIPCHK(ctx, hipFree(ctx->og_buf));
+        ctx->og_buf = nullptr;
+    }
+    if (!ctx->og_buf) {
+        HIPCHK(ctx, hipMalloc(&ctx->og_buf, total));
+        ctx->og_buf_bytes = total;
+    }
+    int32_t *d_dims = nullptr;
+    double *d_cells = nullptr, *d_amps = nullptr, *d_grads = nullptr;
+    float *d_val = nullptr;
+    uint32_t *d_mm = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_dims, (size_t)octaves * 3 * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&d_cells, (size_t)octaves * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_amps, (size_t)octaves * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_grads, ngrad * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&d_val, total * sizeof(float)));
+    HIPCHK(ctx, hipMalloc((void **)&d_mm, 2 * sizeof(uint32_t)));
+    const uint32_t mm0[2] = {0xffffffffu, 0u};
+    HIPCHK(ctx, hipMemcpyAsync(d_dims, dims, (size_t)octaves * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_cells, cells, (size_t)octaves * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_amps, amps, (size_t)octaves * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_grads, grads, ngrad * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_mm, mm0, sizeof mm0, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(noise_eval_kernel, dim3(blocks), dim3(256), 0, ctx->stream, W, H, frames, octaves, d_dims, d_cells, d_amps, d_grads,
+                       d_val, d_mm);
+    hipLaunchKernelGGL(noise_thresh_kernel, dim3(blocks), dim3(256), 0, ctx->stream, total, d_val, d_mm, thresh, ctx->og_buf);
+    HIPCHK(ctx, hipGetLastError());
+    if (og_out) HIPCHK(ctx, hipMemcpyAsync(og_out, ctx->og_buf, total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (void *p : {(void *)d_dims, (void *)d_cells, (void *)d_amps, (void *)d_grads, (void *)d_val, (void *)d_mm}) HIPCHK(ctx, hipFree(p));
+    ctx->W = W;
+    ctx->H = H;
+    ctx->nframes = frames;
+    ctx->og = ctx->og_buf;
+    return RRT_OK;
+}
+
+extern "C" int rrt_select_frame(rrt_ctx *ctx, int32_t frame) {
+    if (!ctx || !ctx->og_buf) return fail(ctx, RRT_E_NOGRID, "rrt_select_frame: no grid");
+    if (frame < 0 || frame >= ctx->nframes) return fail(ctx, RRT_E_ARG, "rrt_select_frame: frame %d of %d", frame, ctx->nframes);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->og = ctx->og_buf + (size_t)frame * ctx->W * ctx->H;
     return RRT_OK;
 }
 

@@ -13,19 +13,34 @@ fade, evaluated with numpy on the host, fully determined by ``seed``.
 """
 import numpy as np
 
-__all__ = ["perlin_occupancygrid", "noise_field", "largest_free_component", "random_connected_pair"]
+__all__ = ["perlin_occupancygrid", "noise_field", "noise_lattices", "DeviceGrids", "largest_free_component", "random_connected_pair"]
 
 
 def _fade(t):
     return t * t * t * (t * (t * 6.0 - 15.0) + 10.0)
 
 
-def _gradient_noise3(shape, cell, rng):
+def noise_lattices(w: int, h: int, frames: int = None, seed: int = 0, base_cell: float = None, octaves: int = 4):
+    """The seeded gradient lattices of the noise field: list of (cell edge in pixels, amplitude, unit gradients
+    (nz, nx, ny, 3)) per octave.  Host and device generators evaluate the same lattices."""
+    rng = np.random.default_rng(seed)
+    f = 1 if frames is None else frames
+    cell = base_cell if base_cell is not None else max(8.0, min(w, h) / 6.0)
+    amp = 1.0
+    out = []
+    for _ in range(octaves):
+        nz, nx, ny = int(np.ceil(f / cell)) + 2, int(np.ceil(w / cell)) + 2, int(np.ceil(h / cell)) + 2
+        g = rng.normal(size=(nz, nx, ny, 3))
+        g /= np.linalg.norm(g, axis=-1, keepdims=True)
+        out.append((float(cell), float(amp), g))
+        amp *= 0.5
+        cell = max(2.0, cell / 2.0)
+    return out
+
+
+def _gradient_noise3(shape, cell, g):
     """One octave of 3-D gradient noise on an integer lattice of spacing `cell` (float64)."""
     f, w, h = shape
-    nz, nx, ny = int(np.ceil(f / cell)) + 2, int(np.ceil(w / cell)) + 2, int(np.ceil(h / cell)) + 2
-    g = rng.normal(size=(nz, nx, ny, 3))
-    g /= np.linalg.norm(g, axis=-1, keepdims=True)
     z = np.arange(f) / cell
     x = np.arange(w) / cell
     y = np.arange(h) / cell
@@ -47,15 +62,10 @@ def _gradient_noise3(shape, cell, rng):
 
 def noise_field(w: int, h: int, frames: int = None, seed: int = 0, base_cell: float = None, octaves: int = 4):
     """Fractal gradient noise, float32, shape (w,h) or (frames,w,h)."""
-    rng = np.random.default_rng(seed)
     f = 1 if frames is None else frames
-    cell = base_cell if base_cell is not None else max(8.0, min(w, h) / 6.0)
     acc = np.zeros((f, w, h))
-    amp = 1.0
-    for _ in range(octaves):
-        acc += amp * _gradient_noise3((f, w, h), cell, rng)
-        amp *= 0.5
-        cell = max(2.0, cell / 2.0)
+    for cell, amp, g in noise_lattices(w, h, frames, seed, base_cell, octaves):
+        acc += amp * _gradient_noise3((f, w, h), cell, g)
     acc = acc.astype(np.float32)
     return acc[0] if frames is None else acc
 
@@ -91,3 +101,25 @@ def random_connected_pair(og: np.ndarray, rnd_gen: np.random.Generator):
     a = cells[rnd_gen.integers(low=0, high=cells.shape[0])]
     b = cells[rnd_gen.integers(low=0, high=cells.shape[0])]
     return a, b
+
+
+class DeviceGrids:
+    """`frames` seeded noise occupancy grids generated ON THE DEVICE and kept resident in HBM
+    (the device-resident counterpart of ``perlin_occupancygrid(w, h, thresh, frames)``, reference oggen.py:7-45).
+
+    ``host`` is the (frames, w, h) int64 copy the planner needs for ``free = argwhere(og == 0)``; it is
+    bit-identical to ``perlin_occupancygrid(w, h, thresh, frames, seed)`` (tests/test_gpu_parity.py).
+    ``planner.set_og_resident(grids, k)`` switches the planner to frame k without any upload
+    (the per-frame ``set_og`` of anim.py:92-93)."""
+
+    def __init__(self, ctx, w: int, h: int, thresh: float = 0.33, frames: int = 1, seed: int = 1, base_cell: float = None,
+                 octaves: int = 4):
+        lat = noise_lattices(w, h, frames, seed, base_cell, octaves)
+        dims = [g.shape[:3] for _, _, g in lat]
+        grads = np.concatenate([g.reshape(-1) for _, _, g in lat])
+        self.ctx = ctx
+        self.host = ctx.noise_grids(w, h, frames, np.float32(thresh), dims, [c for c, _, _ in lat], [a for _, a, _ in lat], grads).astype(np.int64)
+        self.frames = frames
+
+    def select(self, k: int):
+        self.ctx.select_frame(k)

@@ -121,6 +121,23 @@ class RRT(object):
     def set_n(self, n: int):
         self.n = n
 
+    def set_og_resident(self, grids, k: int = 0):
+        """Like set_og(grids.host[k]) for grids generated on this planner's device (oggen.DeviceGrids): frame k
+        becomes the active grid without an upload."""
+        if self._ctx is None or grids.ctx is not self._ctx:
+            raise ValueError("grids were generated on a different device context: use oggen.DeviceGrids(planner.device_context(), ...)")
+        grids.select(k)
+        self.og = grids.host[k]
+        self.free = np.argwhere(self.og == 0)
+        self._grid_dirty = False
+
+    def device_context(self) -> "_ffi.Context":
+        """The planner's device context (created on demand, without uploading a grid)."""
+        if self._ctx is None:
+            self._ctx = _ffi.Context(self.device_id)
+            self._grid_dirty = True
+        return self._ctx
+
     # ------------------------------------------------------------------ device plumbing
     def _device(self) -> "_ffi.Context":
         if self._ctx is None:

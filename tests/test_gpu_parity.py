@@ -298,6 +298,44 @@ def test_full_size_properties_rrtstar_1024_n50000():
     assert np.array_equal(ro.vcost[:live], vc)
 
 
+@pytest.mark.parametrize("w,h,frames,seed", [(200, 200, 1, 1), (1024, 1024, 1, 1), (96, 160, 5, 3), (2048, 2048, 1, 3), (333, 77, 3, 9)])
+def test_device_noise_grids_equal_host_generator(w, h, frames, seed):
+    """Grids generated on the device are bit-identical to the host generator."""
+    from rrtplanner_amd.oggen import DeviceGrids
+
+    ctx = _ffi.Context(0)
+    g = DeviceGrids(ctx, w, h, thresh=0.33, frames=frames, seed=seed)
+    want = perlin_occupancygrid(w, h, thresh=0.33, frames=frames if frames > 1 else None, seed=seed)
+    assert np.array_equal(g.host if frames > 1 else g.host[0], want)
+    ctx.close()
+
+
+def test_replanning_on_resident_frames_equals_uploaded_grids():
+    """anim.py:92-93 pattern: set_og per frame, plan; with DeviceGrids the frames never leave the device."""
+    from rrtplanner_amd.oggen import DeviceGrids
+
+    frames = perlin_occupancygrid(160, 160, thresh=0.33, frames=4, seed=5)
+    xs, xg = random_connected_pair(frames[0], np.random.default_rng(2))
+    a = amd.RRTStar(frames[0], 800, 24, pbar=False, seed=3)
+    b = amd.RRTStar(frames[0], 800, 24, pbar=False, seed=3)
+    grids = DeviceGrids(b.device_context(), 160, 160, thresh=0.33, frames=4, seed=5)
+    for k in range(4):
+        if frames[k][xs[0], xs[1]] or frames[k][xg[0], xg[1]]:
+            continue
+        a.set_og(frames[k])
+        b.set_og_resident(grids, k)
+        try:
+            Ta, ga = a.plan(xs, xg)
+        except IndexError:
+            with pytest.raises(IndexError):
+                b.plan(xs, xg)
+            continue
+        Tb, gb = b.plan(xs, xg)
+        assert ga == gb and list(Ta.edges) == list(Tb.edges)
+        assert all(np.array_equal(Ta.nodes[v]["pt"], Tb.nodes[v]["pt"]) for v in Ta.nodes)
+        assert [d["cost"] for _, _, d in Ta.edges(data=True)] == [d["cost"] for _, _, d in Tb.edges(data=True)]
+
+
 def test_missing_grid_and_bad_arguments_fail_loudly():
     ctx = _ffi.Context(0)
     with pytest.raises(_ffi.RRTError):
