@@ -229,6 +229,35 @@ def test_device_vs_oracle_2048_grid(gpu_ctx, serial):
     _oracle_vs_device(gpu_ctx, og8, 2, 12000, 6, (3, 2044), (2040, 5), 200.5, 40, serial=serial) if og8[3, 2044] == 0 and og8[2040, 5] == 0 else None
 
 
+@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
+def test_fuzz_small_queries_vs_oracle(gpu_ctx, serial):
+    """600 random small queries (grids 8..70 cells wide, n up to 700, radii from 0 to beyond the grid, all three planners, starts
+    on obstacles, n larger than the free space) -- every block-cut / capacity / duplicate / interaction path of the kernels."""
+    rng = np.random.default_rng(20260101)
+    for case in range(600):
+        w, h = int(rng.integers(8, 70)), int(rng.integers(8, 70))
+        dens = rng.choice([0.0, 0.1, 0.3, 0.5])
+        og8 = (rng.uniform(size=(w, h)) < dens).astype(np.uint8)
+        if case % 3 == 0:
+            og8 = oracle.og_u8(perlin_occupancygrid(w, h, seed=case))
+        free = np.argwhere(og8 == 0)
+        if free.shape[0] < 2:
+            continue
+        alg = int(rng.integers(0, 3))
+        n = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 100, 257, 700, 1500]))
+        rr = float(rng.choice([0, 1, 1.5, 3, 7.9, 12, 25, 64, 500]))
+        rg = float(rng.choice([0, 1, 2.5, 6, 15, 100]))
+        xs = free[rng.integers(0, free.shape[0])] if case % 11 else np.array([int(rng.integers(0, w)), int(rng.integers(0, h))])
+        xg = free[rng.integers(0, free.shape[0])]
+        if alg == 2 and (xs == xg).all():
+            continue
+        gpu_ctx.set_grid(og8)
+        try:
+            _oracle_vs_device(gpu_ctx, og8, alg, n, case, xs, xg, rr if alg else None, rg if alg == 2 else None, serial=serial)
+        except AssertionError as e:
+            raise AssertionError(f"fuzz case {case}: grid {w}x{h} dens {dens} alg {alg} n {n} r {rr} rg {rg} xs {xs} xg {xg}") from e
+
+
 def test_batch_of_queries_matches_single_queries(gpu_ctx):
     og = perlin_occupancygrid(512, 512, seed=2)
     og8 = oracle.og_u8(og)
