@@ -518,18 +518,36 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             r.Vs = r.cbest = r.pc = 0.0;
             if (lane < nb) r = brec[lane];  // lane k: sample k
             const bool acc0 = lane < nb && (r.los_s >> 31) != 0 && (r.flags & 1u) == 0;  // accepted if nothing in the block interferes
-            const uint32_t M = r.nnmask | r.rmask | r.dupmask;
             const bool goalhit = informed && lane < nb && dist2(xv, xg) < goal_d2;
             const uint32_t lbit = (lane < BS) ? (1u << lane) : 0u;
             const uint32_t ltmask = lbit - 1u;  // lanes below (meaningless for lanes >= BS, which never use it)
             uint32_t acc_exact = 0;
             int cur = 0;
             bool cut = false;
+            if (lane < nb) newcost[lane] = r.cbest;  // optimistic (snapshot-resolved) cost; exact once the sample has committed
             while (cur < nb && !cut) {
                 // ---- the run of samples [cur, k0) that commit together ----
                 const uint32_t pend = (uint32_t)__ballot(acc0 && lane >= cur);
                 const uint32_t Aopt = acc_exact | (pend & ltmask);  // exact below cur, optimistic in [cur, lane)
-                const bool slow = lane >= cur && lane < nb && ((M & Aopt) != 0 || (goalhit && acc0));
+                // A sample keeps its snapshot result unless an earlier inserted sample of the block is nearer than its nearest,
+                // sits on its cell, or (accepted samples only) would be tried as a parent before the snapshot's choice:
+                // cost-through-it < cost through the snapshot parent (ties go to the lower index = the snapshot, rrt.py:518-521).
+                bool slow = false;
+                if (lane >= cur && lane < nb) {
+                    if (((r.nnmask | r.dupmask) & Aopt) != 0 || (goalhit && acc0)) {
+                        slow = true;
+                    } else if (acc0) {
+                        uint32_t rm = r.rmask & Aopt;
+                        while (rm) {
+                            const int kk = __builtin_ctz(rm);
+                            rm &= rm - 1;
+                            if (newcost[kk] + sqrt_u32(dist2(xq_lds[kk], xv)) < r.cbest) {
+                                slow = true;
+                                break;
+                            }
+                        }
+                    }
+                }
                 const unsigned long long bad = __ballot(slow);
                 int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
                 {
@@ -555,7 +573,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     }
                     if (myacc) {
                         if (star) {
-                            statred[lane * 5 + 2] += r.nnear;
+                            statred[lane * 5 + 2] += r.nnear + (uint32_t)__builtin_popcount(r.rmask & (acc_exact | (racc & ltmask)));
                             statred[lane * 5 + 4] += r.pstat >> 20;
                             statred[lane * 5 + 3] += r.pstat & 0xfffffu;
                         }
