@@ -36,6 +36,9 @@ extern "C" {
 
 #define RRT_FLAG_LOGS 1u   /* keep per-iteration logs (nearest, accept, ellipse cost, j) on the device */
 #define RRT_FLAG_SERIAL 2u /* use the one-sample-per-iteration kernel instead of the 16-sample block kernel */
+#define RRT_FLAG_NOTEAM 4u /* block kernel on ONE workgroup (CU) per query; default: a team of up to 4 CUs per query while
+                              all teams of the batch fit on the device together */
+#define RRT_FLAG_TEAM2 8u  /* teams of 2 CUs (testing) */
 
 typedef struct rrt_ctx rrt_ctx;
 typedef struct rrt_batch rrt_batch;

@@ -24,6 +24,20 @@ RRT_E_COMM = -6
 ALG_STANDARD, ALG_STAR, ALG_INFORMED = 0, 1, 2
 FLAG_LOGS = 1
 FLAG_SERIAL = 2
+FLAG_NOTEAM = 4
+FLAG_TEAM2 = 8
+
+
+def kernel_flags(logs=False, serial=False, team=None):
+    """flags word of rrt_plan / rrt_batch_create: team None = as many CUs per query as fit (up to 4), 1 = one CU, 2 = two."""
+    f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0)
+    if team == 1:
+        f |= FLAG_NOTEAM
+    elif team == 2:
+        f |= FLAG_TEAM2
+    elif team is not None and team != 4:
+        raise ValueError("team must be None, 1, 2 or 4")
+    return f
 
 # every symbol include/rrt_hip.h declares (tests/test_capi_symbols.py checks the library exports them)
 SYMBOLS = (
@@ -209,9 +223,9 @@ class Context:
         _check(self._h, lib().rrt_select_frame(self._h, int(k)))
 
     # ---- one-shot ----
-    def plan(self, query, n, logs=False, serial=False):
+    def plan(self, query, n, logs=False, serial=False, team=None):
         res = ResultArrays(n, logs)
-        flags = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0)
+        flags = kernel_flags(logs, serial, team)
         rc = lib().rrt_plan(self._h, C.byref(query), flags, C.byref(res.c))
         _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
         return rc, res
@@ -262,10 +276,10 @@ class Context:
 class Batch:
     """Q independent queries resident on the device (rrt_batch_*)."""
 
-    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False):
+    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False, team=None):
         self.ctx, self.Q, self.n_cap, self.logs = ctx, int(Q), int(n_cap), logs
         self._h = C.c_void_p()
-        flags = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0)
+        flags = kernel_flags(logs, serial, team)
         _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, flags, C.byref(self._h)))
         self._n = [0] * self.Q
 

@@ -31,8 +31,48 @@
 
 namespace rrtdev {
 
-constexpr int BS = 16;  // samples per block == waves per workgroup
+constexpr int BS = 16;  // samples one workgroup resolves per pass == waves per workgroup
 constexpr int CG = 2;   // cells whose records an owner streams concurrently
+
+// ---- teams: G workgroups (CUs) on one query ---------------------------------------------------------------------
+// A single query is a chain of inserts, but the expensive parts of a block -- scan and owner phase -- only read the
+// snapshot.  A team of G workgroups therefore takes a super-block of 16*G samples: member g scans and resolves samples
+// [16g, 16g+16) on its own CU (own LDS copy of the node cache and of the cell fill counts), hands its 16 records to
+// member 0, whose wave 0 commits all 16*G samples in order (one lane per sample) and publishes the new state; every
+// member then appends the new nodes to its LDS copies.  Two hand-offs per super-block:
+//   records   member g>0 -> member 0: write-through (agent-scope) 8-byte stores, every storing wave drains, workgroup
+//             barrier, ONE lane adds to the arrival counter; wave 0 of member 0 polls it and reads the records with
+//             agent-scope loads (they bypass its L1)
+//   commit    member 0 -> members g>0: plain stores (nodes, costs, parents, cell records, bitmap), agent release,
+//             s_waitcnt, flag; a member polls the flag with one wave, runs ONE agent acquire (drops its L1), waits for it,
+//             joins the workgroup barrier, and only then the workgroup loads.
+// All members must be resident together (the launch keeps teams x G <= CUs); every spin is bounded by a wall-clock
+// limit that fails the query (status ST_TEAM_FAIL) instead of hanging the device.
+constexpr int TEAM_MAX = 4;
+constexpr int TEAM_BYTES = 8192;                 // per query: [arrive | go | fail | state | records], 128-byte lines
+constexpr int TEAM_OFF_ARRIVE = 0, TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384, TEAM_OFF_REC = 512;
+constexpr unsigned long long TEAM_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+typedef __attribute__((address_space(1))) u64 gu64;
+#define RRT_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ u64 lowmask64(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
+
+// One wave polls one word until it reaches `target`; false on timeout or when another member has failed.
+__device__ __forceinline__ bool team_wait(gu32 *word, uint32_t target, gu32 *fail) {
+    const u64 t0 = wall_clock64();
+    for (;;) {
+        if (__hip_atomic_load(word, RRT_RLX_AGENT) >= target) return true;
+        if (__hip_atomic_load(fail, RRT_RLX_AGENT) != 0u) return false;
+        if (wall_clock64() - t0 > TEAM_TIMEOUT_TICKS) {
+            __hip_atomic_store(fail, 1u, RRT_RLX_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
 
 // exact sqrt of an integer below 2^24 (0 included): rsq seed + coupled Goldschmidt / Newton steps in
 // f64.  tests/test_gpu_parity.py checks every input against the host's correctly rounded sqrt.
@@ -59,7 +99,7 @@ __device__ __forceinline__ uint32_t key16(uint32_t node_s, uint32_t q_s, uint32_
     return r;
 }
 
-// Owner's publication for one sample (64 bytes).
+// Owner's publication for one sample (80 bytes = 10 words of 8 bytes).
 struct BRec {
     uint32_t d2s, vs;   // snapshot nearest
     uint32_t los_s;     // line of sight vs -> sample: bit 31 free, low bits cells read
@@ -68,13 +108,18 @@ struct BRec {
     double cbest;       // cost of the sample through its snapshot-resolved parent
     uint32_t vbest;     // snapshot-resolved parent (vs, or the best passing near-set entry)
     uint32_t pstat;     // owner's candidate line-of-sight tests: count << 20 | cells
-    uint32_t nnmask;    // earlier samples of the block strictly nearer than the snapshot nearest
-    uint32_t rmask;     // earlier samples within r_rewire
-    uint32_t dupmask;   // earlier samples on the same cell
     uint32_t nnear;     // |within| over the snapshot
+    uint32_t pad;
     double pc;          // cost of the best passing near-set entry (inf: none, parent is vs)
+    u64 nnmask;         // earlier samples of the (super-)block strictly nearer than the snapshot nearest
+    u64 rmask;          // earlier samples within r_rewire
+    u64 dupmask;        // earlier samples on the same cell
 };
-static_assert(sizeof(BRec) == 64, "BRec must be 64 bytes");
+static_assert(sizeof(BRec) == 80, "BRec must be 80 bytes");
+union BRecWords {
+    BRec r;
+    u64 w[10];
+};
 
 // Block state that wave 0 hands to the other waves after the commit.
 struct BlkState {
@@ -92,19 +137,37 @@ __device__ __forceinline__ void block_scan_step(u32x4 quad, const uint32_t (&xs1
     }
 }
 
+union BlkWords {
+    BlkState b;
+    u64 w[5];
+};
+
+template <int G>
 __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
+    static_assert(G >= 1 && G <= TEAM_MAX, "team size");
+    constexpr int SB = BS * G;  // samples per (super-)block: one lane of the committing wave each
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
-    __shared__ __attribute__((aligned(16))) u32x2 nnx[BS * NWAVE];        // per sample, per wave: {d2, idx}
-    __shared__ __attribute__((aligned(16))) BRec brec[BS];
+    __shared__ __attribute__((aligned(16))) u32x2 nnx[BS * NWAVE];        // per own sample, per wave: {d2, idx}
+    __shared__ __attribute__((aligned(16))) BRec brec[SB];
     __shared__ __attribute__((aligned(16))) BSlot bslots[2 * NWAVE];
     __shared__ __attribute__((aligned(16))) BlkState blk;
-    __shared__ __attribute__((aligned(16))) unsigned long long statred[BS * 5];
-    __shared__ uint32_t xq_lds[BS];
-    __shared__ double newcost[BS];
+    __shared__ __attribute__((aligned(16))) unsigned long long statred[SB * 5];
+    __shared__ uint32_t xq_lds[SB];
+    __shared__ double newcost[SB];
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int q = (int)blockIdx.x;
+    int q = (int)blockIdx.x, g = 0;  // query, team member
+    if (G > 1) {
+        q = (int)blockIdx.x % bv.team_qpad;  // members of one team are 8k blocks apart: dealt to the same XCD (speed only)
+        g = (int)blockIdx.x / bv.team_qpad;
+        if (q >= bv.Q) return;
+    }
     QDesc *D = bv.desc + q;
     if (D->status != ST_RUNNING) return;
+    unsigned char *tb = (G > 1) ? bv.team + (size_t)q * TEAM_BYTES : nullptr;
+    gu32 *const t_arrive = (gu32 *)(tb + TEAM_OFF_ARRIVE), *const t_go = (gu32 *)(tb + TEAM_OFF_GO), *const t_fail = (gu32 *)(tb + TEAM_OFF_FAIL);
+    gu64 *const t_state = (gu64 *)(tb + TEAM_OFF_STATE), *const t_rec = (gu64 *)(tb + TEAM_OFF_REC);
+    uint32_t epoch = 0;  // super-blocks of this launch so far
+    bool team_failed = false;
 
     // ---- per-query views ----
     const int n = D->n, alg = D->alg;
@@ -166,7 +229,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         const uint32_t n0 = nodes_g[0];
         for (int k = t; k < lds_nodes; k += TPB) nodes_lds[k] = (k < j) ? nodes_g[k] : n0;
         for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
-        if (t < BS * 5) statred[t] = 0;
+        if (t < SB * 5) statred[t] = 0;
     }
     __syncthreads();
 
@@ -179,8 +242,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     // wave's HBM list {index, d2, vcost}; the two cheapest entries are found on the fly under a screen that
     // tightens to the second cheapest so far.  Only when both are blocked is the parked list priced and consumed
     // in key order (no second pass over the cells, unless the list overflowed: a radius far beyond the cell size).
-    u32x4 *clist = reinterpret_cast<u32x4 *>(spill) + (size_t)wave * (size_t)(bv.spill_stride / (2 * NWAVE));
-    const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE));
+    const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE * G));  // the engine sizes the spill area per team member
+    u32x4 *clist = reinterpret_cast<u32x4 *>(spill) + (size_t)(g * NWAVE + wave) * (size_t)clist_cap;
     auto snapshot_parent = [&](uint32_t X, int j0, bool check_j0, double bound, double &pc, uint32_t &pi, uint32_t &nnear,
                                uint32_t &ntests, uint32_t &tcells) {
         pc = f64_inf();
@@ -359,7 +422,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 
     while (i < n) {
         const int i0 = i, j0 = j;
-        const int nb = (n - i0) < BS ? (n - i0) : BS;
+        const int nb = (n - i0) < SB ? (n - i0) : SB;  // samples of this (super-)block; lane s of every wave: sample s
         const bool ell = informed && nsoln > 0;
         // ---------------- sample coordinates of the block (rrt.py:421 / :502 / :695-701) ----------------
         if (ell) {
@@ -370,7 +433,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 break;
             }
         }
-        uint32_t xv = 0;  // lane k < nb: sample k
+        ++epoch;
+        uint32_t xv = 0;  // lane s < nb: sample s
         if (lane < nb) {
             if (ell) {
                 const int ui = i0 + lane - ub_offset;
@@ -391,9 +455,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         }
         uint32_t xs16[BS];
 #pragma unroll
-        for (int k = 0; k < BS; ++k) {
-            uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
-            if (k >= nb) X = (uint32_t)__builtin_amdgcn_readlane((int)xv, 0);
+        for (int k = 0; k < BS; ++k) {  // this member's samples [16g, 16g+16)
+            const int sk = g * BS + k;
+            uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)xv, sk);
+            if (sk >= nb) X = (uint32_t)__builtin_amdgcn_readlane((int)xv, 0);
             xs16[k] = X << 4;
         }
 
@@ -446,7 +511,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 ((RRT_LDS u32x2 *)nnx)[lane * NWAVE + wave] = v;
             }
         }
-        if (t < BS) xq_lds[t] = xv;  // lane k: sample k (k < nb)
+        if (t < SB) xq_lds[t] = xv;  // lane s: sample s (s < nb)
         STAMP(0);
         __syncthreads();
         STAMP(1);
@@ -455,9 +520,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #ifdef RRT_STAMPS
         const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
-        if (wave < nb) {
+        const int sidx = g * BS + wave;  // the sample this wave owns
+        if (sidx < nb) {
             const int k = wave;
-            const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);  // every wave holds the same xv
+            const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, sidx);  // every wave holds the same xv
             uint32_t d2s = NONE, vs = NONE;
             if (lane < NWAVE) {
                 const u32x2 v = ((RRT_LDS u32x2 *)nnx)[k * NWAVE + lane];
@@ -471,11 +537,11 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             int cells = 0;
             const bool free_s = los_wave(og, H, node_xy(vs), Xk, lane, cells);
             // earlier samples of this block that could interact once inserted
-            const uint32_t xo = (lane < k) ? xq_lds[lane] : Xk;
+            const uint32_t xo = (lane < sidx) ? xq_lds[lane] : Xk;
             const uint32_t dk = dist2(xo, Xk);
-            const uint32_t nnmask = (uint32_t)__ballot(lane < k && dk < d2s);
-            const uint32_t rmask = (uint32_t)__ballot(lane < k && star && dk < r2);
-            const uint32_t dupmask = (uint32_t)__ballot(lane < k && xo == Xk);
+            const u64 nnmask = __ballot(lane < sidx && dk < d2s);
+            const u64 rmask = __ballot(lane < sidx && star && dk < r2);
+            const u64 dupmask = __ballot(lane < sidx && xo == Xk);
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
             const double cnear_s = Vs + sqrt_u32(d2s);
@@ -500,10 +566,19 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.rmask = rmask;
                 r.dupmask = dupmask;
                 r.nnear = nnear;
+                r.pad = 0;
                 r.pc = pc;
-                brec[k] = r;
+                if (G == 1 || g == 0) {
+                    brec[sidx] = r;
+                } else {  // write-through 8-byte stores; drained below, before the workgroup's arrival
+                    BRecWords u;
+                    u.r = r;
+#pragma unroll
+                    for (int w = 0; w < 10; ++w) __hip_atomic_store(t_rec + (size_t)sidx * 10 + w, u.w[w], RRT_RLX_AGENT);
+                }
             }
         }
+        if (G > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the barrier
 #ifdef RRT_STAMPS
         wcyc_acc += __builtin_amdgcn_s_memtime() - tb0;
 #endif
@@ -511,24 +586,71 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         __syncthreads();
         STAMP(3);
 
-        // ---------------- C: commit (wave 0) ----------------
+        // ---------------- team members g > 0: hand the records over, wait for the commit, take the new nodes ----------------
+        if (G > 1 && g > 0) {
+            if (t == 0) __hip_atomic_fetch_add(t_arrive, 1u, RRT_RLX_AGENT);  // after every wave's drain and the barrier
+            if (wave == 0) {
+                const bool ok = team_wait(t_go, epoch, t_fail);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
+                if (lane == 0) blk.pad0 = ok ? 0 : 1;
+            }
+            __syncthreads();
+            if (blk.pad0 != 0) {
+                team_failed = true;
+                break;
+            }
+            BlkWords u;
+#pragma unroll
+            for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + w, RRT_RLX_AGENT);  // vector loads past the L1
+            i = u.b.i;
+            nsoln = u.b.nsoln;
+            vbest_soln = u.b.vbest_soln;
+            cmin_soln = u.b.cmin_soln;
+            c_ell = u.b.c_ell;
+            const int jn = u.b.j;
+            if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
+                const uint32_t Xn = nodes_g[j0 + t];
+                if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
+                if (star) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            j = jn;
+            __syncthreads();
+            continue;
+        }
+
+        // ---------------- C: commit (wave 0 of member 0) ----------------
         if (wave == 0) {
+            bool remote_ok = true;
+            if (G > 1) {  // the other members' records: poll the arrival counter, then loads that bypass the L1
+                remote_ok = team_wait(t_arrive, (uint32_t)(G - 1) * epoch, t_fail);
+                if (remote_ok && lane >= BS && lane < nb) {
+                    BRecWords u;
+#pragma unroll
+                    for (int w = 0; w < 10; ++w) u.w[w] = __hip_atomic_load(t_rec + (size_t)lane * 10 + w, RRT_RLX_AGENT);
+                    brec[lane] = u.r;
+                }
+            }
+            if (!remote_ok) {
+                if (lane == 0) blk.pad0 = 1;
+            } else {
             BRec r;
-            r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnmask = r.rmask = r.dupmask = r.nnear = 0;
+            r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnear = r.pad = 0;
+            r.nnmask = r.rmask = r.dupmask = 0;
             r.Vs = r.cbest = r.pc = 0.0;
-            if (lane < nb) r = brec[lane];  // lane k: sample k
+            if (lane < nb) r = brec[lane];  // lane s: sample s
             const bool acc0 = lane < nb && (r.los_s >> 31) != 0 && (r.flags & 1u) == 0;  // accepted if nothing in the block interferes
             const bool goalhit = informed && lane < nb && dist2(xv, xg) < goal_d2;
-            const uint32_t lbit = (lane < BS) ? (1u << lane) : 0u;
-            const uint32_t ltmask = lbit - 1u;  // lanes below (meaningless for lanes >= BS, which never use it)
-            uint32_t acc_exact = 0;
+            const u64 lbit = 1ull << lane;
+            const u64 ltmask = lbit - 1ull;  // lanes below
+            u64 acc_exact = 0;
             int cur = 0;
             bool cut = false;
             if (lane < nb) newcost[lane] = r.cbest;  // optimistic (snapshot-resolved) cost; exact once the sample has committed
             while (cur < nb && !cut) {
                 // ---- the run of samples [cur, k0) that commit together ----
-                const uint32_t pend = (uint32_t)__ballot(acc0 && lane >= cur);
-                const uint32_t Aopt = acc_exact | (pend & ltmask);  // exact below cur, optimistic in [cur, lane)
+                const u64 pend = __ballot(acc0 && lane >= cur);
+                const u64 Aopt = acc_exact | (pend & ltmask);  // exact below cur, optimistic in [cur, lane)
                 // A sample keeps its snapshot result unless an earlier inserted sample of the block is nearer than its nearest,
                 // sits on its cell, or (accepted samples only) would be tried as a parent before the snapshot's choice:
                 // cost-through-it < cost through the snapshot parent (ties go to the lower index = the snapshot, rrt.py:518-521).
@@ -537,9 +659,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     if (((r.nnmask | r.dupmask) & Aopt) != 0 || (goalhit && acc0)) {
                         slow = true;
                     } else if (acc0) {
-                        uint32_t rm = r.rmask & Aopt;
+                        u64 rm = r.rmask & Aopt;
                         while (rm) {
-                            const int kk = __builtin_ctz(rm);
+                            const int kk = __builtin_ctzll(rm);
                             rm &= rm - 1;
                             if (newcost[kk] + sqrt_u32(dist2(xq_lds[kk], xv)) < r.cbest) {
                                 slow = true;
@@ -551,15 +673,15 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 const unsigned long long bad = __ballot(slow);
                 int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
                 {
-                    const uint32_t range = ((1u << k0) - 1u) & ~((1u << cur) - 1u);  // k0 <= 16
-                    if (j + __builtin_popcount(pend & range) > n) k0 = cur;  // would overfill: take the exact serial path
+                    const u64 range = lowmask64(k0) & ~lowmask64(cur);
+                    if (j + __builtin_popcountll(pend & range) > n) k0 = cur;  // would overfill: take the exact serial path
                 }
                 if (k0 > cur) {
-                    const uint32_t range = ((1u << k0) - 1u) & ~((1u << cur) - 1u);
-                    const uint32_t racc = pend & range;
+                    const u64 range = lowmask64(k0) & ~lowmask64(cur);
+                    const u64 racc = pend & range;
                     const bool inr = lane >= cur && lane < k0;
                     const bool myacc = inr && acc0;
-                    const int jmine = j + __builtin_popcount(racc & ltmask);  // j as this sample sees it
+                    const int jmine = j + __builtin_popcountll(racc & ltmask);  // j as this sample sees it
                     if (inr) {
                         statred[lane * 5 + 0] += (unsigned long long)jmine;
                         statred[lane * 5 + 1] += (unsigned long long)(r.los_s & 0x7fffffffu);
@@ -573,7 +695,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     }
                     if (myacc) {
                         if (star) {
-                            statred[lane * 5 + 2] += r.nnear + (uint32_t)__builtin_popcount(r.rmask & (acc_exact | (racc & ltmask)));
+                            statred[lane * 5 + 2] += r.nnear + (uint32_t)__builtin_popcountll(r.rmask & (acc_exact | (racc & ltmask)));
                             statred[lane * 5 + 4] += r.pstat >> 20;
                             statred[lane * 5 + 3] += r.pstat & 0xfffffu;
                         }
@@ -593,7 +715,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         }
                     }
                     acc_exact |= racc;
-                    j += __builtin_popcount(racc);
+                    j += __builtin_popcountll(racc);
                     cur = k0;
                 }
                 if (cur >= nb) break;
@@ -610,10 +732,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     double pc = rk.pc;
                     uint32_t pi = (rk.pc < f64_inf()) ? rk.vbest : NONE, nnear = rk.nnear;
                     uint32_t ntests = rk.pstat >> 20, tcells = rk.pstat & 0xfffffu;
-                    const uint32_t xo = (lane < BS) ? xq_lds[lane] : Xk;  // lane kk: sample kk
+                    const uint32_t xo = (lane < SB) ? xq_lds[lane] : Xk;  // lane kk: sample kk
                     const uint32_t dk = dist2(xo, Xk);
                     const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_exact) != 0;
-                    const uint32_t nm = rk.nnmask & acc_exact;
+                    const u64 nm = rk.nnmask & acc_exact;
                     bool nn_inblock = false;
                     if (nm) {  // nearest is an inserted block node: smallest distance, earliest sample on ties
                         uint32_t kd = (nm & lbit) ? dk : NONE;
@@ -621,7 +743,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         wave_min_key_idx(kd, kk);
                         nn_inblock = true;
                         d2n = kd;
-                        vn = (uint32_t)j0 + (uint32_t)__builtin_popcount(acc_exact & ((1u << kk) - 1u));
+                        vn = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & lowmask64((int)kk));
                         Vn = newcost[kk];
                         int cc = 0;
                         nocoll = los_wave(og, H, (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk), Xk, lane, cc);  // rrt.py:424
@@ -644,14 +766,14 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             }
                         }
                         // inserted block nodes within r_rewire, in (cost, index) order, while they beat the snapshot's best
-                        uint32_t rm = rk.rmask & acc_exact;
-                        nnear += (uint32_t)__builtin_popcount(rm);
+                        u64 rm = rk.rmask & acc_exact;
+                        nnear += (uint32_t)__builtin_popcountll(rm);
                         while (rm) {
                             double cn = f64_inf();
                             uint32_t ci = NONE;
                             if (rm & lbit) {
                                 cn = newcost[lane] + sqrt_u32(dk);
-                                ci = (uint32_t)j0 + (uint32_t)__builtin_popcount(acc_exact & ltmask);
+                                ci = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & ltmask);
                                 if (!(cn < cnear)) {
                                     cn = f64_inf();
                                     ci = NONE;
@@ -661,9 +783,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             if (ci == NONE || !key_lt(cn, ci, pc, pi)) break;
                             uint32_t kk = 0;  // which sample is node ci
                             {
-                                uint32_t am = acc_exact;
+                                u64 am = acc_exact;
                                 for (uint32_t c = 0; c < ci - (uint32_t)j0; ++c) am &= am - 1;
-                                kk = (uint32_t)__builtin_ctz(am);
+                                kk = (uint32_t)__builtin_ctzll(am);
                             }
                             int cc = 0;
                             const bool ok = los_wave(og, H, (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk), Xk, lane, cc);  // rrt.py:519
@@ -674,7 +796,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                                 pi = ci;
                                 break;
                             }
-                            rm &= ~(1u << kk);
+                            rm &= ~(1ull << kk);
                         }
                         if (pi != NONE) {
                             vbest = pi;
@@ -724,7 +846,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             }
                             if (first) cut = true;  // sampling switches from free space to the ellipse (rrt.py:695)
                         }
-                        acc_exact |= 1u << k;
+                        acc_exact |= 1ull << k;
                         j++;
                     }
                     cur = k + 1;
@@ -741,12 +863,28 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 b.cmin_soln = cmin_soln;
                 b.c_ell = c_ell;
                 blk = b;
+                if (G > 1) {  // state first (write-through), then everything the commit stored, then the flag
+                    BlkWords u;
+                    u.b = b;
+#pragma unroll
+                    for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + w, u.w[w], RRT_RLX_AGENT);
+                }
             }
+            if (G > 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // wave 0 made every store of the commit
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the flag must not overtake the write-back
+                if (lane == 0) __hip_atomic_store(t_go, epoch, RRT_RLX_AGENT);
+            }
+            }  // remote_ok
         }
         STAMP(4);
         __syncthreads();
         {
             const BlkState b = blk;
+            if (G > 1 && b.pad0 != 0) {
+                team_failed = true;
+                break;
+            }
             i = b.i;
             j = b.j;
             nsoln = b.nsoln;
@@ -755,6 +893,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             c_ell = b.c_ell;
         }
     }
+
+    if (G > 1 && g > 0) return;  // member 0 finishes the query (its copies of the state are the committed ones)
+    if (team_failed) status = ST_TEAM_FAIL;
 
     // cell fill counts back to HBM (a resumed launch reloads them); fold wave 0's statistics
     for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
@@ -784,7 +925,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 
     if (t == 0) {
         unsigned long long s[5] = {0, 0, 0, 0, 0};
-        for (int l = 0; l < BS; ++l)
+        for (int l = 0; l < SB; ++l)
             for (int c = 0; c < 5; ++c) s[c] += statred[l * 5 + c];
         D->status = status;
         D->i = i;

@@ -31,6 +31,7 @@ struct rrt_ctx {
     rrt_batch *single = nullptr;  // batch behind rrt_plan / rrt_plan_resume
     uint32_t single_flags = 0;
     int max_lds = 0;
+    int num_cu = 0;
 };
 
 struct rrt_batch {
@@ -41,6 +42,9 @@ struct rrt_batch {
     bool use_block = false;     // block-parallel kernel (rrt_block.h) instead of the one-sample-per-iteration kernel
     int32_t blk_lds_chunks = 1; // node chunks cached in LDS by the block kernel
     size_t blk_lds_bytes = 0;
+    int32_t team = 1;           // workgroups (CUs) per query of the block kernel (rrt_block.h, teams)
+    int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
+    unsigned char *d_team = nullptr;  // [Q][TEAM_BYTES] sync words, state, exchanged records; zeroed before every launch
     QDesc *d_desc = nullptr;
     std::vector<QDesc> h_desc;
     uint32_t *d_samples = nullptr, *d_nodes = nullptr, *d_bitmap = nullptr;
@@ -57,6 +61,9 @@ struct rrt_batch {
     bool timed = false;
     std::vector<uint32_t> stage;  // host staging for packed samples
 };
+
+static const void *block_kernel_of(int team);
+static size_t block_kernel_static_lds(int team);
 
 static int fail(rrt_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -88,6 +95,7 @@ extern "C" int rrt_ctx_create(int32_t device_id, rrt_ctx **out) {
     c->device = device_id;
     HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(nullptr, hipDeviceGetAttribute(&c->max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id));
+    HIPCHK(nullptr, hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device_id));
     *out = c;
     return RRT_OK;
 }
@@ -285,7 +293,8 @@ extern "C" int rrt_batch_destroy(rrt_batch *b) {
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     void *ptrs[] = {b->d_desc,  b->d_samples,   b->d_slab,        b->d_bitmap, b->d_unitball,  b->d_cellrec,
-                    b->d_spill, b->d_cbest_log, b->d_nearest_log, b->d_j_log,  b->d_accept_log, b->d_cellcnt};
+                    b->d_spill, b->d_cbest_log, b->d_nearest_log, b->d_j_log,  b->d_accept_log, b->d_cellcnt,
+                    b->d_team};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -312,11 +321,18 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->node_stride = ((n_cap + 1 + CHUNK - 1) / CHUNK) * CHUNK;
     b->bitmap_words = (int32_t)(((size_t)ctx->W * ctx->H + 31) / 32);
     int chunks = (n_cap + 1 + CHUNK - 1) / CHUNK;
-    b->spill_stride = chunks * CHUNK;  // 256 overflow entries per wave and node chunk; also go2goal's cost array
+    b->use_block = !(flags & RRT_FLAG_SERIAL);
+    if (b->use_block && !(flags & RRT_FLAG_NOTEAM)) {
+        // a team of 4 (2) CUs per query while every member of every team can be resident at once; teams are laid out
+        // member-major over Q rounded up to 8 so that the members of a team land on one XCD
+        b->team_qpad = (Q + 7) & ~7;
+        if (flags & RRT_FLAG_TEAM2) b->team = (b->team_qpad * 2 <= ctx->num_cu) ? 2 : 1;
+        else b->team = (b->team_qpad * 4 <= ctx->num_cu) ? 4 : ((b->team_qpad * 2 <= ctx->num_cu) ? 2 : 1);
+    }
+    b->spill_stride = chunks * CHUNK * b->team;  // per member: 256 parked entries per wave and node chunk; also go2goal's cost array
     {   // block kernel LDS: [node cache | cell fill counts 16 KiB]
-        const size_t budget = (size_t)ctx->max_lds - 8192;  // static LDS of the kernel
+        const size_t budget = (size_t)ctx->max_lds - block_kernel_static_lds(b->team);
         const size_t fixed = (size_t)MAX_CELLS * sizeof(uint32_t);
-        b->use_block = !(flags & RRT_FLAG_SERIAL);
         if (b->use_block) {
             int nc = (int)((budget - fixed) / ((size_t)CHUNK * sizeof(uint32_t)));
             b->blk_lds_chunks = nc > chunks ? chunks : nc;
@@ -348,6 +364,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     if (b->use_block) {
         ALLOC(b->d_cellrec, q * (size_t)b->rec_stride * sizeof(uint4));
         ALLOC(b->d_cellcnt, q * (size_t)MAX_CELLS * sizeof(uint32_t));
+        if (b->team > 1) ALLOC(b->d_team, q * (size_t)TEAM_BYTES);
     }
     if (flags & RRT_FLAG_LOGS) {
         ALLOC(b->d_nearest_log, q * n_cap * sizeof(int32_t));
@@ -478,7 +495,24 @@ static BatchView make_view(rrt_batch *b) {
     v.cellrec = b->d_cellrec;
     v.cellcnt = b->d_cellcnt;
     v.rec_stride = b->rec_stride;
+    v.team = b->d_team;
+    v.Q = b->Q;
+    v.team_qpad = b->team_qpad;
     return v;
+}
+
+static const void *block_kernel_of(int team) {
+    switch (team) {
+        case 4: return reinterpret_cast<const void *>(rrt_expand_block_kernel<4>);
+        case 2: return reinterpret_cast<const void *>(rrt_expand_block_kernel<2>);
+        default: return reinterpret_cast<const void *>(rrt_expand_block_kernel<1>);
+    }
+}
+
+static size_t block_kernel_static_lds(int team) {
+    hipFuncAttributes a{};
+    if (hipFuncGetAttributes(&a, block_kernel_of(team)) != hipSuccess) return 16384;
+    return (a.sharedSizeBytes + 255) & ~(size_t)255;
 }
 
 static size_t expand_lds_bytes(int lds_chunks) {
@@ -495,11 +529,16 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
     if (b->use_block) {
         v.lds_chunks = b->blk_lds_chunks;
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rrt_expand_block_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
+        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(b->team), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+        if (b->team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
-        hipLaunchKernelGGL(rrt_expand_block_kernel, dim3((unsigned)b->Q), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        if (b->team == 4)
+            hipLaunchKernelGGL(rrt_expand_block_kernel<4>, dim3((unsigned)(b->team_qpad * 4)), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        else if (b->team == 2)
+            hipLaunchKernelGGL(rrt_expand_block_kernel<2>, dim3((unsigned)(b->team_qpad * 2)), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        else
+            hipLaunchKernelGGL(rrt_expand_block_kernel<1>, dim3((unsigned)b->Q), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;
@@ -584,6 +623,9 @@ extern "C" int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out) {
             HIPCHK(ctx, hipMemcpyAsync(out->j_log, b->d_j_log + o, (size_t)ni * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (d.status == ST_TEAM_FAIL)
+        return fail(ctx, RRT_E_HIP, "query %d: the %d workgroups of its team were not resident together (a hand-off timed out); "
+                    "use RRT_FLAG_NOTEAM when other kernels share the device", q, b->team);
     return d.status < 0 ? d.status : RRT_OK;
 }
 

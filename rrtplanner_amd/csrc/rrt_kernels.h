@@ -29,7 +29,7 @@
 
 namespace rrtdev {
 
-enum : int32_t { ST_DONE = 0, ST_NEED_UB = 1, ST_UNREACHABLE = -2, ST_RUNNING = 100, ST_IDLE = 101 };
+enum : int32_t { ST_DONE = 0, ST_NEED_UB = 1, ST_UNREACHABLE = -2, ST_TEAM_FAIL = -3, ST_RUNNING = 100, ST_IDLE = 101 };
 
 // Per-query descriptor in HBM: inputs, resumable loop state, statistics.
 struct QDesc {
@@ -65,6 +65,8 @@ struct BatchView {
     uint4 *cellrec;           // [Q][rec_stride]    block kernel: per-cell arrays of {xy, index, vcost} records
     uint32_t *cellcnt;        // [Q][MAX_CELLS]     fill counts of the cells
     int64_t rec_stride;
+    unsigned char *team;      // [Q][TEAM_BYTES]    block kernel with teams: sync words, state, exchanged records
+    int32_t Q, team_qpad;     // queries of the batch; Q rounded up to a multiple of 8 (block = member * team_qpad + query)
 };
 
 constexpr int MAX_CELLS = 4096;  // cells per query (their fill counts live in LDS: 16 KiB)

@@ -143,7 +143,11 @@ def test_replan_chain_rng_continues_and_set_og(tag):
 
 
 # ------------------------------------------------------------------------------- device vs oracle, larger
-def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None, serial=False):
+KERNELS = ["team", "team2", "block", "serial"]  # 4 CUs per query (default), 2 CUs, 1 CU, one sample per iteration
+_KERNEL_ARGS = {"team": {}, "team2": {"team": 2}, "block": {"team": 1}, "serial": {"serial": True}}
+
+
+def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None, kernel="team"):
     rng = np.random.default_rng(seed)
     free = np.argwhere(og8 == 0)
     samples = hostprep.draw_free_samples(rng, free, n)
@@ -151,7 +155,7 @@ def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None
     gd2 = hostprep.goal_threshold(r_goal) if r_goal is not None else 0
     Cm = hostprep.rotation_to_world_frame(np.asarray(xs, dtype=np.int64), np.asarray(xg, dtype=np.int64)) if alg == 2 else None
     q, keep = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2, goal_d2=gd2, Cmat=Cm)
-    rc, res = ctx.plan(q, n, logs=True, serial=serial)
+    rc, res = ctx.plan(q, n, logs=True, **_KERNEL_ARGS[kernel])
     st, ro = oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=r2, r_goal=r_goal or 0.0, Cmat=Cm)
     ub = None
     if rc == _ffi.RRT_NEED_UNITBALL:
@@ -173,64 +177,64 @@ def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None
     return res, ro
 
 
-@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("alg,rr,rg", [(0, None, None), (1, 64, None), (2, 64, 12)])
-def test_device_vs_oracle_1024_n6000(gpu_ctx, alg, rr, rg, serial):
+def test_device_vs_oracle_1024_n6000(gpu_ctx, alg, rr, rg, kernel):
     og = perlin_occupancygrid(1024, 1024, seed=1)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)
     xs, xg = random_connected_pair(og, np.random.default_rng(7))
-    _oracle_vs_device(gpu_ctx, og8, alg, 6000, 0, xs, xg, rr, rg, serial=serial)
+    _oracle_vs_device(gpu_ctx, og8, alg, 6000, 0, xs, xg, rr, rg, kernel=kernel)
 
 
-@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
-def test_device_vs_oracle_beyond_lds_capacity(gpu_ctx, serial):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_device_vs_oracle_beyond_lds_capacity(gpu_ctx, kernel):
     """n = 40000 exceeds the LDS-resident node chunks: the scan crosses from LDS chunks into HBM chunks."""
     og = perlin_occupancygrid(1024, 1024, seed=1)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)
     xs, xg = random_connected_pair(og, np.random.default_rng(7))
-    _oracle_vs_device(gpu_ctx, og8, 1, 40000, 0, xs, xg, 64, None, serial=serial)
+    _oracle_vs_device(gpu_ctx, og8, 1, 40000, 0, xs, xg, 64, None, kernel=kernel)
 
 
-@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
-def test_device_vs_oracle_near_set_spills(gpu_ctx, serial):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_device_vs_oracle_near_set_spills(gpu_ctx, kernel):
     """r_rewire far beyond the grid: the near set is the whole tree and overflows the LDS lists."""
     og = perlin_occupancygrid(256, 256, seed=4)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)
     xs, xg = random_connected_pair(og, np.random.default_rng(1))
-    _oracle_vs_device(gpu_ctx, og8, 1, 5000, 3, xs, xg, 1e6, None, serial=serial)
+    _oracle_vs_device(gpu_ctx, og8, 1, 5000, 3, xs, xg, 1e6, None, kernel=kernel)
 
 
-@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("alg,rr,rg,grid,n,seed", [
     (1, 9, None, 64, 3000, 1),      # tiny grid: most samples are duplicates or interact inside a block
     (2, 30, 8, 96, 2500, 2),        # informed on a small grid: many ellipse changes cut blocks
     (1, 200, None, 300, 4000, 3),   # radius comparable to the grid
     (0, None, None, 40, 1500, 4),   # n close to the number of free cells
 ])
-def test_device_vs_oracle_dense_interactions(gpu_ctx, alg, rr, rg, grid, n, seed, serial):
+def test_device_vs_oracle_dense_interactions(gpu_ctx, alg, rr, rg, grid, n, seed, kernel):
     og = perlin_occupancygrid(grid, grid, seed=seed)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)
     xs, xg = random_connected_pair(og, np.random.default_rng(seed))
-    _oracle_vs_device(gpu_ctx, og8, alg, n, seed, xs, xg, rr, rg, serial=serial)
+    _oracle_vs_device(gpu_ctx, og8, alg, n, seed, xs, xg, rr, rg, kernel=kernel)
 
 
-@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
-def test_device_vs_oracle_2048_grid(gpu_ctx, serial):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_device_vs_oracle_2048_grid(gpu_ctx, kernel):
     """The largest supported grid (BASELINE config 5's size): squared distances use all 23 key bits."""
     og = perlin_occupancygrid(2048, 2048, seed=3)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)
     xs, xg = random_connected_pair(og, np.random.default_rng(11))
-    _oracle_vs_device(gpu_ctx, og8, 1, 30000, 5, xs, xg, 64, None, serial=serial)
-    _oracle_vs_device(gpu_ctx, og8, 2, 12000, 6, (3, 2044), (2040, 5), 200.5, 40, serial=serial) if og8[3, 2044] == 0 and og8[2040, 5] == 0 else None
+    _oracle_vs_device(gpu_ctx, og8, 1, 30000, 5, xs, xg, 64, None, kernel=kernel)
+    _oracle_vs_device(gpu_ctx, og8, 2, 12000, 6, (3, 2044), (2040, 5), 200.5, 40, kernel=kernel) if og8[3, 2044] == 0 and og8[2040, 5] == 0 else None
 
 
-@pytest.mark.parametrize("serial", [False, True], ids=["block", "serial"])
-def test_fuzz_small_queries_vs_oracle(gpu_ctx, serial):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_fuzz_small_queries_vs_oracle(gpu_ctx, kernel):
     """600 random small queries (grids 8..70 cells wide, n up to 700, radii from 0 to beyond the grid, all three planners, starts
     on obstacles, n larger than the free space) -- every block-cut / capacity / duplicate / interaction path of the kernels."""
     rng = np.random.default_rng(20260101)
@@ -253,7 +257,7 @@ def test_fuzz_small_queries_vs_oracle(gpu_ctx, serial):
             continue
         gpu_ctx.set_grid(og8)
         try:
-            _oracle_vs_device(gpu_ctx, og8, alg, n, case, xs, xg, rr if alg else None, rg if alg == 2 else None, serial=serial)
+            _oracle_vs_device(gpu_ctx, og8, alg, n, case, xs, xg, rr if alg else None, rg if alg == 2 else None, kernel=kernel)
         except AssertionError as e:
             raise AssertionError(f"fuzz case {case}: grid {w}x{h} dens {dens} alg {alg} n {n} r {rr} rg {rg} xs {xs} xg {xg}") from e
 
