@@ -31,7 +31,7 @@
 
 namespace rrtdev {
 
-constexpr int BS = 16;  // samples one workgroup resolves per pass == waves per workgroup
+constexpr int BS = 16;  // samples one workgroup resolves per pass (one owner wave each): 16 alone or in a team of up to 4, 8 / 4 in a team of 8 / 16
 constexpr int CG = 2;   // cells whose records an owner streams concurrently
 
 // ---- teams: G workgroups (CUs) on one query ---------------------------------------------------------------------
@@ -40,17 +40,17 @@ constexpr int CG = 2;   // cells whose records an owner streams concurrently
 // [16g, 16g+16) on its own CU (own LDS copy of the node cache and of the cell fill counts), hands its 16 records to
 // member 0, whose wave 0 commits all 16*G samples in order (one lane per sample) and publishes the new state; every
 // member then appends the new nodes to its LDS copies.  Two hand-offs per super-block:
-//   records   member g>0 -> member 0: write-through (agent-scope) 8-byte stores, every storing wave drains, workgroup
-//             barrier, ONE lane adds to the arrival counter; wave 0 of member 0 polls it and reads the records with
-//             agent-scope loads (they bypass its L1)
+//   records   member g>0 -> member 0: owners leave their record in LDS; after the workgroup barrier ONE wave writes the 16
+//             records write-through (agent-scope stores, whole 128-byte lines), drains, and stores the member's arrival
+//             flag; wave 0 of member 0 polls the flags and reads the records with agent-scope loads (they bypass its L1)
 //   commit    member 0 -> members g>0: plain stores (nodes, costs, parents, cell records, bitmap), agent release,
 //             s_waitcnt, flag; a member polls the flag with one wave, runs ONE agent acquire (drops its L1), waits for it,
 //             joins the workgroup barrier, and only then the workgroup loads.
 // All members must be resident together (the launch keeps teams x G <= CUs); every spin is bounded by a wall-clock
 // limit that fails the query (status ST_TEAM_FAIL) instead of hanging the device.
-constexpr int TEAM_MAX = 4;
-constexpr int TEAM_BYTES = 8192;                 // per query: [arrive | go | fail | state | records], 128-byte lines
-constexpr int TEAM_OFF_ARRIVE = 0, TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384, TEAM_OFF_REC = 512;
+constexpr int TEAM_MAX = 16;
+constexpr int TEAM_BYTES = 8192;                 // per query: [go | fail | state | records | arrival flags], 128-byte lines
+constexpr int TEAM_OFF_ARRIVE = 6144, TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384, TEAM_OFF_REC = 512;
 constexpr unsigned long long TEAM_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
 
 typedef unsigned long long u64;
@@ -59,6 +59,21 @@ typedef __attribute__((address_space(1))) u64 gu64;
 #define RRT_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 __device__ __forceinline__ u64 lowmask64(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
+
+// One wave polls the arrival flags of members 1..G-1 (lane g: member g's flag, 128 bytes apart) until all have reached `target`.
+__device__ __forceinline__ bool team_wait_all(gu32 *flags, int G, uint32_t target, gu32 *fail, int lane) {
+    const u64 t0 = wall_clock64();
+    for (;;) {
+        const bool mine = (lane >= 1 && lane < G) ? __hip_atomic_load(flags + 32 * lane, RRT_RLX_AGENT) >= target : true;
+        if (__all(mine)) return true;
+        if (__hip_atomic_load(fail, RRT_RLX_AGENT) != 0u) return false;
+        if (wall_clock64() - t0 > TEAM_TIMEOUT_TICKS) {
+            __hip_atomic_store(fail, 1u, RRT_RLX_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
 
 // One wave polls one word until it reaches `target`; false on timeout or when another member has failed.
 __device__ __forceinline__ bool team_wait(gu32 *word, uint32_t target, gu32 *fail) {
@@ -127,10 +142,11 @@ struct BlkState {
     double cmin_soln, c_ell;
 };
 
-__device__ __forceinline__ void block_scan_step(u32x4 quad, const uint32_t (&xs16)[BS], uint32_t (&best)[BS], uint32_t tag0) {
+template <int BSM>
+__device__ __forceinline__ void block_scan_step(u32x4 quad, const uint32_t (&xs16)[BSM], uint32_t (&best)[BSM], uint32_t tag0) {
     const uint32_t n0 = quad.x << 4, n1 = quad.y << 4, n2 = quad.z << 4, n3 = quad.w << 4;
 #pragma unroll
-    for (int k = 0; k < BS; ++k) {
+    for (int k = 0; k < BSM; ++k) {
         const uint32_t k0 = key16(n0, xs16[k], tag0), k1 = key16(n1, xs16[k], tag0 + 1), k2 = key16(n2, xs16[k], tag0 + 2),
                        k3 = key16(n3, xs16[k], tag0 + 3);
         best[k] = min(min(best[k], k0), min(min(k1, k2), k3));
@@ -142,12 +158,12 @@ union BlkWords {
     u64 w[5];
 };
 
-template <int G>
+template <int G, int BSM>
 __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
-    static_assert(G >= 1 && G <= TEAM_MAX, "team size");
-    constexpr int SB = BS * G;  // samples per (super-)block: one lane of the committing wave each
+    static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM <= BS && BSM * G <= 64, "team size");
+    constexpr int SB = BSM * G;  // samples per (super-)block: one lane of the committing wave each; BSM per member
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
-    __shared__ __attribute__((aligned(16))) u32x2 nnx[BS * NWAVE];        // per own sample, per wave: {d2, idx}
+    __shared__ __attribute__((aligned(16))) u32x2 nnx[BSM * NWAVE];        // per own sample, per wave: {d2, idx}
     __shared__ __attribute__((aligned(16))) BRec brec[SB];
     __shared__ __attribute__((aligned(16))) BSlot bslots[2 * NWAVE];
     __shared__ __attribute__((aligned(16))) BlkState blk;
@@ -375,48 +391,162 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             lbc = tt.c2;
             lbi = tt.i2 + 1;
             if (nlist > clist_cap) continue;  // the list overflowed: stream the cells again above the new lower bound
-            // both blocked: price the parked entries once (in place: {index, -, cost}; +inf = out), then consume them
-            // two at a time in key order
-            for (uint32_t p = (uint32_t)lane; p < nlist; p += 64) {
-                const u32x4 e = clist[p];  // {index, d2, vcost}
+            // both blocked: price the parked entries once and compact the ones still open (cost < bound, key >= lower bound) to
+            // the front of the list as {index, cells, cost}.  A sample behind a wall has dozens of cheaper-but-blocked
+            // candidates; two per memory round trip made it the straggler of its block, so the rest is tested up to 8 lines of
+            // sight at a time:
+            //   <= 16 open entries: rank them in (cost, index) order and test ranks 0-7, 8-15 (one wave per line of sight)
+            //   more: every entry is tested, one line of sight per LANE.
+            uint32_t nval = 0;
+            for (uint32_t p0 = 0; p0 < nlist; p0 += 64) {
+                const uint32_t p = p0 + (uint32_t)lane;
+                u32x4 e = {NONE, 0u, 0u, 0u};
+                if (p < nlist) e = clist[p];  // {index, d2, vcost}
                 const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
                 double cn = f64_inf();
-                if ((float)V + __builtin_amdgcn_sqrtf((float)e.y) < boundf) {
+                if (p < nlist && (float)V + __builtin_amdgcn_sqrtf((float)e.y) < boundf) {
                     const double c = V + sqrt_u24(e.y);
                     if (c < bound && !key_lt(c, e.x, lbc, lbi)) cn = c;
                 }
-                const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
-                clist[p] = u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)};
+                const bool open = cn < bound;
+                const unsigned long long om = __ballot(open);
+                if (open) {  // positions at or below the ones this iteration has read
+                    const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
+                    clist[nval + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)};
+                }
+                nval += (uint32_t)__builtin_popcountll(om);
             }
-            for (;;) {
-                Top2 t2;
-                t2.init();
-                for (uint32_t p = (uint32_t)lane; p < nlist; p += 64) {
+            if (nval == 0) return;  // every entry was tried
+            const bool batch = rad < 64;  // every near-set segment fits one 64-cell ballot
+            double wc = f64_inf();        // cheapest passing entry (only the group that ends the search can hold one)
+            uint32_t wi = NONE;
+            if (nval <= 16) {
+                u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
+                if ((uint32_t)lane < nval) e = clist[lane];
+                const unsigned long long kb = ((unsigned long long)e.w << 32) | e.z;  // non-negative doubles order like their bits
+                uint32_t rank = 0;
+                for (uint32_t jn = 0; jn < nval; ++jn) {
+                    const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)e.w, (int)jn) << 32) |
+                                                  (uint32_t)__builtin_amdgcn_readlane((int)e.z, (int)jn);
+                    const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)jn);
+                    rank += (kj < kb || (kj == kb && ij < e.x)) ? 1u : 0u;
+                }
+                const uint32_t step = batch ? (uint32_t)LOSB : 1u;
+                for (uint32_t r0 = 0; r0 < nval; r0 += step) {
+                    unsigned long long m = __ballot((uint32_t)lane < nval && rank >= r0 && rank < r0 + step);
+                    uint32_t ci[LOSB], cxy[LOSB], clo[LOSB], chi[LOSB];
+                    int nc = 0;
+#pragma unroll
+                    for (int c = 0; c < LOSB; ++c) {
+                        ci[c] = NONE;
+                        cxy[c] = X;
+                        clo[c] = 0u;
+                        chi[c] = 0x7ff00000u;
+                        if (m != 0) {
+                            const int src = (int)__builtin_ctzll(m);
+                            m &= m - 1;
+                            ci[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.x, src);
+                            clo[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.z, src);
+                            chi[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.w, src);
+                            nc = c + 1;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < LOSB; ++c)
+                        if (c < nc) cxy[c] = node_xy(ci[c]);
+                    bool okc[LOSB];
+                    int ccs[LOSB];
+                    if (batch) {
+                        los_batch(og, H, cxy, nc, X, lane, okc, ccs);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < LOSB; ++c) {
+                            okc[c] = false;
+                            ccs[c] = 0;
+                        }
+                        okc[0] = los_wave(og, H, cxy[0], X, lane, ccs[0]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < LOSB; ++c) {
+                        const double cc = __longlong_as_double((long long)(((unsigned long long)chi[c] << 32) | clo[c]));
+                        if (c < nc && okc[c] && key_lt(cc, ci[c], wc, wi)) {
+                            wc = cc;
+                            wi = ci[c];
+                        }
+                    }
+                    // statistics as the sequential loop counts them: the tests up to and including the first passing entry
+#pragma unroll
+                    for (int c = 0; c < LOSB; ++c) {
+                        const double cc = __longlong_as_double((long long)(((unsigned long long)chi[c] << 32) | clo[c]));
+                        if (c < nc && (wi == NONE || !key_lt(wc, wi, cc, ci[c]))) {
+                            ntests += 1;
+                            tcells += (uint32_t)ccs[c];
+                        }
+                    }
+                    if (wi != NONE) break;
+                }
+                pc = wc;
+                pi = wi;
+                return;
+            }
+            // many open entries: one line of sight PER LANE, 64 entries at a time, every entry tested (each lane walks its own
+            // segment, four cell loads in flight); the answer is the cheapest passing entry
+            for (uint32_t p0 = 0; p0 < nval; p0 += 64) {
+                const uint32_t p = p0 + (uint32_t)lane;
+                const bool have = p < nval;
+                u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
+                if (have) e = clist[p];
+                const uint32_t axy = have ? node_xy(e.x) : X;
+                const rrt_line_t ln = rrt_line_setup(ux(axy), uy(axy), ux(X), uy(X));
+                const int L = ln.major;
+                bool blocked = false;
+                int cells = L + 1;
+                for (int k0 = 0; __any(!blocked && k0 <= L); k0 += 4) {
+                    uint8_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {  // unconditional loads (clamped to the segment's last cell)
+                        const int kk = (k0 + u) < L ? (k0 + u) : L;
+                        int x, y;
+                        rrt_line_cell(&ln, kk, &x, &y);
+                        v[u] = og[(size_t)x * H + y];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (!blocked && k0 + u <= L && v[u] != 0) {
+                            blocked = true;
+                            cells = k0 + u + 1;
+                        }
+                }
+                if (have) clist[p].y = (uint32_t)cells;  // cells read by this test, for the statistics pass
+                double cn = f64_inf();
+                uint32_t ci = NONE;
+                if (have && !blocked) {
+                    cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                    ci = e.x;
+                }
+                wave_min_f64_idx(cn, ci);
+                if (ci != NONE && key_lt(cn, ci, wc, wi)) {
+                    wc = cn;
+                    wi = ci;
+                }
+            }
+            // statistics as the sequential loop counts them: the tests up to and including the first passing entry
+            {
+                uint32_t nt = 0, tcl = 0;
+                for (uint32_t p = (uint32_t)lane; p < nval; p += 64) {
                     const u32x4 e = clist[p];
                     const double cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
-                    if (cn < bound && !key_lt(cn, e.x, lbc, lbi)) t2.fold(cn, e.x);
+                    if (wi == NONE || !key_lt(wc, wi, cn, e.x)) {
+                        nt += 1;
+                        tcl += e.y;
+                    }
                 }
-                t2.wave_reduce();
-                if (t2.i1 == NONE) return;  // every entry was tried
-                los_wave2(og, H, node_xy(t2.i1), t2.i2 != NONE ? node_xy(t2.i2) : X, t2.i2 != NONE, X, lane, ok1, cc1, ok2, cc2);
-                ntests += 1;
-                tcells += (uint32_t)cc1;
-                if (ok1) {
-                    pc = t2.c1;
-                    pi = t2.i1;
-                    return;
-                }
-                if (t2.i2 == NONE) return;
-                ntests += 1;
-                tcells += (uint32_t)cc2;
-                if (ok2) {
-                    pc = t2.c2;
-                    pi = t2.i2;
-                    return;
-                }
-                lbc = t2.c2;
-                lbi = t2.i2 + 1;
+                ntests += wave_sum_u32(nt);
+                tcells += wave_sum_u32(tcl);
             }
+            pc = wc;
+            pi = wi;
+            return;
         }
     };
 
@@ -453,10 +583,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 xv = samples[i0 + lane];
             }
         }
-        uint32_t xs16[BS];
+        uint32_t xs16[BSM];
 #pragma unroll
-        for (int k = 0; k < BS; ++k) {  // this member's samples [16g, 16g+16)
-            const int sk = g * BS + k;
+        for (int k = 0; k < BSM; ++k) {  // this member's samples [BSM g, BSM (g + 1))
+            const int sk = g * BSM + k;
             uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)xv, sk);
             if (sk >= nb) X = (uint32_t)__builtin_amdgcn_readlane((int)xv, 0);
             xs16[k] = X << 4;
@@ -465,9 +595,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         // ---------------- A: scan the snapshot for all samples of the block ----------------
         const int nsteps = (j0 + CHUNK - 1) / CHUNK;
         {
-            uint32_t best[BS];
+            uint32_t best[BSM];
 #pragma unroll
-            for (int k = 0; k < BS; ++k) best[k] = NONE;
+            for (int k = 0; k < BSM; ++k) best[k] = NONE;
             const int nl = nsteps < lds_chunks ? nsteps : lds_chunks;
             if (nl > 0) {
                 u32x4 cur = nodes_lds4[t];
@@ -491,7 +621,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             // carries its lowest such index); gathered into lanes 0..15
             uint32_t gd = NONE, gi = NONE;
 #pragma unroll
-            for (int k = 0; k < BS; ++k) {
+            for (int k = 0; k < BSM; ++k) {
                 const uint32_t key = best[k];
                 const uint32_t d2m = wave_min_u32(key) >> 8;
                 const uint32_t tag = key & 0xffu;
@@ -506,7 +636,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     gi = ki;
                 }
             }
-            if (lane < BS) {
+            if (lane < BSM) {
                 u32x2 v = {gd, gi};
                 ((RRT_LDS u32x2 *)nnx)[lane * NWAVE + wave] = v;
             }
@@ -520,8 +650,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #ifdef RRT_STAMPS
         const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
-        const int sidx = g * BS + wave;  // the sample this wave owns
-        if (sidx < nb) {
+        const int sidx = g * BSM + wave;  // the sample this wave owns (waves BSM.. of a small-BSM team member idle here)
+        if (wave < BSM && sidx < nb) {
             const int k = wave;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, sidx);  // every wave holds the same xv
             uint32_t d2s = NONE, vs = NONE;
@@ -568,17 +698,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.nnear = nnear;
                 r.pad = 0;
                 r.pc = pc;
-                if (G == 1 || g == 0) {
-                    brec[sidx] = r;
-                } else {  // write-through 8-byte stores; drained below, before the workgroup's arrival
-                    BRecWords u;
-                    u.r = r;
-#pragma unroll
-                    for (int w = 0; w < 10; ++w) __hip_atomic_store(t_rec + (size_t)sidx * 10 + w, u.w[w], RRT_RLX_AGENT);
-                }
+                brec[sidx] = r;
             }
         }
-        if (G > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the barrier
 #ifdef RRT_STAMPS
         wcyc_acc += __builtin_amdgcn_s_memtime() - tb0;
 #endif
@@ -588,8 +710,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 
         // ---------------- team members g > 0: hand the records over, wait for the commit, take the new nodes ----------------
         if (G > 1 && g > 0) {
-            if (t == 0) __hip_atomic_fetch_add(t_arrive, 1u, RRT_RLX_AGENT);  // after every wave's drain and the barrier
             if (wave == 0) {
+                // this member's 16 records, LDS -> HBM: whole 128-byte lines per wave instruction, write-through (8-byte
+                // stores of single lanes are partial-line fabric writes and delay everything queued behind them)
+                const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[g * BSM];
+                for (int w = lane; w < BSM * 10; w += 64) __hip_atomic_store(t_rec + (size_t)g * BSM * 10 + w, src[w], RRT_RLX_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
+                if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
                 const bool ok = team_wait(t_go, epoch, t_fail);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
@@ -623,8 +750,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         if (wave == 0) {
             bool remote_ok = true;
             if (G > 1) {  // the other members' records: poll the arrival counter, then loads that bypass the L1
-                remote_ok = team_wait(t_arrive, (uint32_t)(G - 1) * epoch, t_fail);
-                if (remote_ok && lane >= BS && lane < nb) {
+                remote_ok = team_wait_all(t_arrive, G, epoch, t_fail, lane);
+                if (remote_ok && lane >= BSM && lane < nb) {
                     BRecWords u;
 #pragma unroll
                     for (int w = 0; w < 10; ++w) u.w[w] = __hip_atomic_load(t_rec + (size_t)lane * 10 + w, RRT_RLX_AGENT);

@@ -171,4 +171,29 @@ __device__ __forceinline__ void los_wave2(const uint8_t *__restrict__ og, int H,
     if (has1) ok1 = los_wave(og, H, a1, b, lane, cells1);
 }
 
+// Up to LOSB lines of sight a[c] -> b at once (c < nc, wave-uniform operands), every segment shorter than 64 cells
+// (one ballot each): all cell loads are in flight together.  cells[c] as in los_wave.
+constexpr int LOSB = 8;
+__device__ __forceinline__ void los_batch(const uint8_t *__restrict__ og, int H, const uint32_t (&a)[LOSB], int nc, uint32_t b, int lane,
+                                          bool (&ok)[LOSB], int (&cells)[LOSB]) {
+    rrt_line_t ln[LOSB];
+    uint8_t v[LOSB];
+#pragma unroll
+    for (int c = 0; c < LOSB; ++c) {
+        ln[c] = rrt_line_setup(ux(a[c]), uy(a[c]), ux(b), uy(b));
+        v[c] = 0;
+        if (c < nc && lane <= ln[c].major) {
+            int x, y;
+            rrt_line_cell(&ln[c], lane, &x, &y);
+            v[c] = og[(size_t)x * H + y];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LOSB; ++c) {
+        const unsigned long long mb = __ballot(v[c] != 0);
+        ok[c] = mb == 0;
+        cells[c] = mb ? (int)__builtin_ctzll(mb) + 1 : ln[c].major + 1;
+    }
+}
+
 }  // namespace rrtdev

@@ -326,8 +326,11 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         // a team of 4 (2) CUs per query while every member of every team can be resident at once; teams are laid out
         // member-major over Q rounded up to 8 so that the members of a team land on one XCD
         b->team_qpad = (Q + 7) & ~7;
-        if (flags & RRT_FLAG_TEAM2) b->team = (b->team_qpad * 2 <= ctx->num_cu) ? 2 : 1;
-        else b->team = (b->team_qpad * 4 <= ctx->num_cu) ? 4 : ((b->team_qpad * 2 <= ctx->num_cu) ? 2 : 1);
+        int want = (flags & RRT_FLAG_TEAM2) ? 2 : 16;
+        if (const char *e = getenv("RRT_TEAM")) want = atoi(e);  // experiments: cap the team size
+        b->team = 1;
+        for (int g : {2, 4, 8, 16})
+            if (g <= want && b->team_qpad * g <= ctx->num_cu) b->team = g;
     }
     b->spill_stride = chunks * CHUNK * b->team;  // per member: 256 parked entries per wave and node chunk; also go2goal's cost array
     {   // block kernel LDS: [node cache | cell fill counts 16 KiB]
@@ -503,9 +506,11 @@ static BatchView make_view(rrt_batch *b) {
 
 static const void *block_kernel_of(int team) {
     switch (team) {
-        case 4: return reinterpret_cast<const void *>(rrt_expand_block_kernel<4>);
-        case 2: return reinterpret_cast<const void *>(rrt_expand_block_kernel<2>);
-        default: return reinterpret_cast<const void *>(rrt_expand_block_kernel<1>);
+        case 16: return reinterpret_cast<const void *>(rrt_expand_block_kernel<16, 4>);
+        case 8: return reinterpret_cast<const void *>(rrt_expand_block_kernel<8, 8>);
+        case 4: return reinterpret_cast<const void *>(rrt_expand_block_kernel<4, 16>);
+        case 2: return reinterpret_cast<const void *>(rrt_expand_block_kernel<2, 16>);
+        default: return reinterpret_cast<const void *>(rrt_expand_block_kernel<1, 16>);
     }
 }
 
@@ -533,12 +538,17 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         if (b->team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
-        if (b->team == 4)
-            hipLaunchKernelGGL(rrt_expand_block_kernel<4>, dim3((unsigned)(b->team_qpad * 4)), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        const dim3 tg((unsigned)(b->team_qpad * b->team));
+        if (b->team == 16)
+            hipLaunchKernelGGL((rrt_expand_block_kernel<16, 4>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        else if (b->team == 8)
+            hipLaunchKernelGGL((rrt_expand_block_kernel<8, 8>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        else if (b->team == 4)
+            hipLaunchKernelGGL((rrt_expand_block_kernel<4, 16>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
         else if (b->team == 2)
-            hipLaunchKernelGGL(rrt_expand_block_kernel<2>, dim3((unsigned)(b->team_qpad * 2)), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+            hipLaunchKernelGGL((rrt_expand_block_kernel<2, 16>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
         else
-            hipLaunchKernelGGL(rrt_expand_block_kernel<1>, dim3((unsigned)b->Q), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+            hipLaunchKernelGGL((rrt_expand_block_kernel<1, 16>), dim3((unsigned)b->Q), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;
