@@ -252,30 +252,32 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     auto node_xy = [&](uint32_t v) -> uint32_t { return ((int)v < lds_nodes) ? nodes_lds[v] : nodes_g[v]; };
     auto cell_of = [&](uint32_t X) -> int { return (ux(X) >> cshift) * ncy + (uy(X) >> cshift); };
 
-    // Snapshot near set of sample X: first entry in (cost, index) order with cost < bound and a free line of
-    // sight.  One whole wave.  Returns (pc, pi) or (inf, NONE); nnear = |within| over nodes [0, j0).
-    // The cell records are streamed once.  Every entry whose vcost alone is below the bound is parked in this
-    // wave's HBM list {index, d2, vcost}; the two cheapest entries are found on the fly under a screen that
-    // tightens to the second cheapest so far.  Only when both are blocked is the parked list priced and consumed
-    // in key order (no second pass over the cells, unless the list overflowed: a radius far beyond the cell size).
+    // ---- the near set of one sample (within :176-181, choose parent :511-521) ----------------------------------------
+    // First entry in (cost, index) order with cost < bound and a free line of sight, over the snapshot nodes [0, j0).
+    // Three steps, used by one wave on its own (snapshot_parent) or by the waves of a sample's group (owner phase of
+    // teams whose members hold fewer samples than waves):
+    //   stream_cells   the 16-byte records of the cells the radius ball touches are streamed once (this wave's share of the
+    //                  cells).  Every entry whose vcost alone is below the bound is parked in this wave's HBM list
+    //                  {index, d2, vcost}; the two cheapest entries are found on the fly under a screen that tightens to
+    //                  the second cheapest so far.
+    //   consume_list   only when both are blocked: the parked list is priced and the entries still open are tested.
+    //   count_tests    the statistics as the sequential loop counts them.
     const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE * G));  // the engine sizes the spill area per team member
-    u32x4 *clist = reinterpret_cast<u32x4 *>(spill) + (size_t)(g * NWAVE + wave) * (size_t)clist_cap;
-    auto snapshot_parent = [&](uint32_t X, int j0, bool check_j0, double bound, double &pc, uint32_t &pi, uint32_t &nnear,
-                               uint32_t &ntests, uint32_t &tcells) {
-        pc = f64_inf();
-        pi = NONE;
-        nnear = 0;
-        if (r2 == 0) return;
+    u32x4 *const clist_base = reinterpret_cast<u32x4 *>(spill) + (size_t)(g * NWAVE) * (size_t)clist_cap;  // this member's 16 lists
+    u32x4 *const clist = clist_base + (size_t)wave * (size_t)clist_cap;
+    // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
+    auto screen_of = [](double c) -> float { return (float)c * (1.0f + 1.0e-6f) + 4.0e-3f; };
+    auto hi_of = [](double c) -> uint32_t { return (uint32_t)((unsigned long long)__double_as_longlong(c) >> 32); };
+    const float FINF = __uint_as_float(0x7f800000u);
+
+    auto stream_cells = [&](uint32_t X, int j0, bool check_j0, double bound, double lbc, uint32_t lbi, int part, int nparts, Top2 &tt,
+                            uint32_t &nnear_part, uint32_t &nlist) {
         const int x = ux(X), y = uy(X);
         const int cx0 = (x - rad < 0 ? 0 : x - rad) >> cshift, cx1 = (x + rad > W - 1 ? W - 1 : x + rad) >> cshift;
         const int cy0 = (y - rad < 0 ? 0 : y - rad) >> cshift, cy1 = (y + rad > H - 1 ? H - 1 : y + rad) >> cshift;
         const int ny = cy1 - cy0 + 1, ncr = (cx1 - cx0 + 1) * ny;
-        // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
-        auto screen_of = [](double c) -> float { return (float)c * (1.0f + 1.0e-6f) + 4.0e-3f; };
-        auto hi_of = [](double c) -> uint32_t { return (uint32_t)((unsigned long long)__double_as_longlong(c) >> 32); };
         const float boundf = screen_of(bound);
         const uint32_t boundhi = hi_of(bound);  // vcost >= bound  <=>  its high word > boundhi or (== and ...): `<=` keeps a superset
-        const float FINF = __uint_as_float(0x7f800000u);
         // the cells of the ball's bounding box: lane c (< ncr, first 64) holds cell c's fill count and record offset
         uint32_t tcnt = 0, toff = 0;
         if (lane < ncr) {
@@ -283,91 +285,255 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             tcnt = cellcnt[cell];
             toff = (uint32_t)cell * (uint32_t)ccap;
         }
+        tt.init();
+        float m1 = FINF, m2 = FINF;  // this lane's two cheapest verified entries, rounded up to f32
+        uint32_t hits = 0;
+        nlist = 0;
+        float T = boundf;            // wave-uniform screen, tightens to the second cheapest so far
+        uint32_t Thi = hi_of((double)boundf);
+        for (int c0 = part * CG; c0 < ncr; c0 += nparts * CG) {  // CG cells at a time: CG independent record loads in flight
+            uint32_t cnt[CG];
+            const u32x4 *rec[CG];
+            uint32_t maxc = 0;
+#pragma unroll
+            for (int g2 = 0; g2 < CG; ++g2) {
+                cnt[g2] = 0;
+                rec[g2] = cellrec;
+                if (c0 + g2 < ncr) {
+                    if (c0 + g2 < 64) {
+                        cnt[g2] = (uint32_t)__builtin_amdgcn_readlane((int)tcnt, c0 + g2);
+                        rec[g2] = cellrec + (uint32_t)__builtin_amdgcn_readlane((int)toff, c0 + g2);
+                    } else {  // more than 64 cells: a radius far beyond the cell size
+                        const int ci = c0 + g2, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
+                        cnt[g2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cellcnt[cell]);
+                        rec[g2] = cellrec + (size_t)cell * (size_t)ccap;
+                    }
+                }
+                maxc = cnt[g2] > maxc ? cnt[g2] : maxc;
+            }
+            for (uint32_t s0 = 0; s0 < maxc; s0 += 64) {
+                const uint32_t s = s0 + (uint32_t)lane;
+                u32x4 rc[CG];
+                // unconditional loads (a clamped slot of the same cell; every cell array has at least one slot) so that
+                // all CG loads are issued back to back; lanes past the fill count get a far-away point afterwards
+#pragma unroll
+                for (int g2 = 0; g2 < CG; ++g2) rc[g2] = rec[g2][s < cnt[g2] ? s : 0u];  // {xy, index, vcost}
+#pragma unroll
+                for (int g2 = 0; g2 < CG; ++g2)
+                    if (!(s < cnt[g2])) rc[g2].x = 0x7fff7fffu;  // never within the radius
+                bool dirty = false;
+#pragma unroll
+                for (int g2 = 0; g2 < CG; ++g2) {
+                    const uint32_t d2 = dist2(rc[g2].x, X);
+                    const bool hit = d2 < r2 && (!check_j0 || rc[g2].y < (uint32_t)j0);
+                    hits += hit ? 1u : 0u;
+                    // park everything whose vcost alone can be below the bound (the high word of a non-negative f64 is monotone)
+                    const bool park = hit && rc[g2].w <= boundhi;
+                    const unsigned long long pm = __ballot(park);
+                    if (pm == 0) continue;
+                    if (park) {
+                        const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+                        if (pos < clist_cap) clist[pos] = u32x4{rc[g2].y, d2, rc[g2].z, rc[g2].w};
+                    }
+                    nlist += (uint32_t)__builtin_popcountll(pm);
+                    // screens, cheapest first; none rejects an entry that belongs to the two cheapest
+                    const bool pre = park && rc[g2].w <= Thi;
+                    if (__ballot(pre) == 0) continue;
+                    const double V = __longlong_as_double((long long)(((unsigned long long)rc[g2].w << 32) | rc[g2].z));
+                    const bool maybe = pre && ((float)V + __builtin_amdgcn_sqrtf((float)d2) < T);
+                    if (__ballot(maybe) == 0) continue;
+                    if (maybe) {
+                        const double cn = V + sqrt_u24(d2);
+                        if (cn < bound && !key_lt(cn, rc[g2].y, lbc, lbi)) {  // rrt.py:518, strict
+                            tt.fold(cn, rc[g2].y);
+                            const float cu = screen_of(cn);
+                            if (cu < m1) {
+                                m2 = m1;
+                                m1 = cu;
+                            } else if (cu < m2) {
+                                m2 = cu;
+                            }
+                        }
+                    }
+                    dirty = true;
+                }
+                if (dirty) {  // tighten the screen to (an upper bound of) the wave's second cheapest so far
+                    const float w1 = wave_min_f32_nonneg(m1);
+                    const float w2 = wave_min_f32_nonneg(m1 == w1 ? m2 : m1);
+                    T = w2 < boundf ? w2 : boundf;
+                    Thi = hi_of((double)T);
+                }
+            }
+        }
+        nnear_part = wave_sum_u32(hits);
+        tt.wave_reduce();
+    };
+
+    // Price this wave's parked entries once and compact the ones still open (cost < bound, key >= lower bound) to the front
+    // of the list as {index, cells, cost}, then test them.  A sample behind a wall has dozens of cheaper-but-blocked
+    // candidates; two per memory round trip made it the straggler of its block:
+    //   <= 16 open entries: rank them in (cost, index) order and test ranks 0-7, 8-15 (one wave per line of sight, 8 in flight)
+    //   more: every entry is tested, one line of sight per LANE.
+    // (wc, wi) = the cheapest passing entry; every entry with a key up to it has been tested and holds its cell count.
+    auto consume_list = [&](uint32_t X, double bound, double lbc, uint32_t lbi, uint32_t nlist, double &wc, uint32_t &wi, uint32_t &nval) {
+        const float boundf = screen_of(bound);
+        nval = 0;
+        wc = f64_inf();
+        wi = NONE;
+        for (uint32_t p0 = 0; p0 < nlist; p0 += 64) {
+            const uint32_t p = p0 + (uint32_t)lane;
+            u32x4 e = {NONE, 0u, 0u, 0u};
+            if (p < nlist) e = clist[p];  // {index, d2, vcost}
+            const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+            double cn = f64_inf();
+            if (p < nlist && (float)V + __builtin_amdgcn_sqrtf((float)e.y) < boundf) {
+                const double c = V + sqrt_u24(e.y);
+                if (c < bound && !key_lt(c, e.x, lbc, lbi)) cn = c;
+            }
+            const bool open = cn < bound;
+            const unsigned long long om = __ballot(open);
+            if (open) {  // positions at or below the ones this iteration has read
+                const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
+                clist[nval + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)};
+            }
+            nval += (uint32_t)__builtin_popcountll(om);
+        }
+        if (nval == 0) return;  // every entry was tried
+        const bool batch = rad < 64;  // every near-set segment fits one 64-cell ballot
+        if (nval <= 16) {
+            u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
+            if ((uint32_t)lane < nval) e = clist[lane];
+            const unsigned long long kb = ((unsigned long long)e.w << 32) | e.z;  // non-negative doubles order like their bits
+            uint32_t rank = 0;
+            for (uint32_t jn = 0; jn < nval; ++jn) {
+                const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)e.w, (int)jn) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane((int)e.z, (int)jn);
+                const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)jn);
+                rank += (kj < kb || (kj == kb && ij < e.x)) ? 1u : 0u;
+            }
+            const uint32_t step = batch ? (uint32_t)LOSB : 1u;
+            for (uint32_t r0 = 0; r0 < nval; r0 += step) {
+                unsigned long long m = __ballot((uint32_t)lane < nval && rank >= r0 && rank < r0 + step);
+                uint32_t ci[LOSB], cxy[LOSB], clo[LOSB], chi[LOSB];
+                int src[LOSB];
+                int nc = 0;
+#pragma unroll
+                for (int c = 0; c < LOSB; ++c) {
+                    ci[c] = NONE;
+                    cxy[c] = X;
+                    clo[c] = 0u;
+                    chi[c] = 0x7ff00000u;
+                    src[c] = 0;
+                    if (m != 0) {
+                        src[c] = (int)__builtin_ctzll(m);
+                        m &= m - 1;
+                        ci[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.x, src[c]);
+                        clo[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.z, src[c]);
+                        chi[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.w, src[c]);
+                        nc = c + 1;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < LOSB; ++c)
+                    if (c < nc) cxy[c] = node_xy(ci[c]);
+                bool okc[LOSB];
+                int ccs[LOSB];
+                if (batch) {
+                    los_batch(og, H, cxy, nc, X, lane, okc, ccs);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < LOSB; ++c) {
+                        okc[c] = false;
+                        ccs[c] = 0;
+                    }
+                    okc[0] = los_wave(og, H, cxy[0], X, lane, ccs[0]);
+                }
+#pragma unroll
+                for (int c = 0; c < LOSB; ++c) {
+                    if (c < nc) {
+                        if (lane == src[c]) clist[lane].y = (uint32_t)ccs[c];  // cells read by this test, for count_tests
+                        const double cc = __longlong_as_double((long long)(((unsigned long long)chi[c] << 32) | clo[c]));
+                        if (okc[c] && key_lt(cc, ci[c], wc, wi)) {
+                            wc = cc;
+                            wi = ci[c];
+                        }
+                    }
+                }
+                if (wi != NONE) break;
+            }
+            return;
+        }
+        // many open entries: one line of sight PER LANE, 64 entries at a time, every entry tested (each lane walks its own
+        // segment, four cell loads in flight); the answer is the cheapest passing entry
+        for (uint32_t p0 = 0; p0 < nval; p0 += 64) {
+            const uint32_t p = p0 + (uint32_t)lane;
+            const bool have = p < nval;
+            u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
+            if (have) e = clist[p];
+            const uint32_t axy = have ? node_xy(e.x) : X;
+            const rrt_line_t ln = rrt_line_setup(ux(axy), uy(axy), ux(X), uy(X));
+            const int L = ln.major;
+            bool blocked = false;
+            int cells = L + 1;
+            for (int k0 = 0; __any(!blocked && k0 <= L); k0 += 4) {
+                uint8_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // unconditional loads (clamped to the segment's last cell)
+                    const int kk = (k0 + u) < L ? (k0 + u) : L;
+                    int x, y;
+                    rrt_line_cell(&ln, kk, &x, &y);
+                    v[u] = og[(size_t)x * H + y];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (!blocked && k0 + u <= L && v[u] != 0) {
+                        blocked = true;
+                        cells = k0 + u + 1;
+                    }
+            }
+            if (have) clist[p].y = (uint32_t)cells;  // cells read by this test, for count_tests
+            double cn = f64_inf();
+            uint32_t ci = NONE;
+            if (have && !blocked) {
+                cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                ci = e.x;
+            }
+            wave_min_f64_idx(cn, ci);
+            if (ci != NONE && key_lt(cn, ci, wc, wi)) {
+                wc = cn;
+                wi = ci;
+            }
+        }
+    };
+
+    // The tests the sequential loop makes over a consumed list: up to and including the first passing entry (wc, wi), or all.
+    auto count_tests = [&](const u32x4 *list, uint32_t nval, double wc, uint32_t wi, uint32_t &ntests, uint32_t &tcells) {
+        uint32_t nt = 0, tcl = 0;
+        for (uint32_t p = (uint32_t)lane; p < nval; p += 64) {
+            const u32x4 e = list[p];
+            const double cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+            if (wi == NONE || !key_lt(wc, wi, cn, e.x)) {
+                nt += 1;
+                tcl += e.y;
+            }
+        }
+        ntests += wave_sum_u32(nt);
+        tcells += wave_sum_u32(tcl);
+    };
+
+    // One whole wave on its own.  Returns (pc, pi) or (inf, NONE); nnear = |within| over nodes [0, j0).
+    auto snapshot_parent = [&](uint32_t X, int j0, bool check_j0, double bound, double &pc, uint32_t &pi, uint32_t &nnear,
+                               uint32_t &ntests, uint32_t &tcells) {
+        pc = f64_inf();
+        pi = NONE;
+        nnear = 0;
+        if (r2 == 0) return;
         double lbc = -1.0;
         uint32_t lbi = 0;
         for (;;) {
             Top2 tt;
-            tt.init();
-            float m1 = FINF, m2 = FINF;  // this lane's two cheapest verified entries, rounded up to f32
-            uint32_t hits = 0, nlist = 0;
-            float T = boundf;            // wave-uniform screen, tightens to the second cheapest so far
-            uint32_t Thi = hi_of((double)boundf);
-            for (int c0 = 0; c0 < ncr; c0 += CG) {  // CG cells at a time: CG independent record loads in flight
-                uint32_t cnt[CG];
-                const u32x4 *rec[CG];
-                uint32_t maxc = 0;
-#pragma unroll
-                for (int g = 0; g < CG; ++g) {
-                    cnt[g] = 0;
-                    rec[g] = cellrec;
-                    if (c0 + g < ncr) {
-                        if (c0 + g < 64) {
-                            cnt[g] = (uint32_t)__builtin_amdgcn_readlane((int)tcnt, c0 + g);
-                            rec[g] = cellrec + (uint32_t)__builtin_amdgcn_readlane((int)toff, c0 + g);
-                        } else {  // more than 64 cells: a radius far beyond the cell size
-                            const int ci = c0 + g, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
-                            cnt[g] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cellcnt[cell]);
-                            rec[g] = cellrec + (size_t)cell * (size_t)ccap;
-                        }
-                    }
-                    maxc = cnt[g] > maxc ? cnt[g] : maxc;
-                }
-                for (uint32_t s0 = 0; s0 < maxc; s0 += 64) {
-                    const uint32_t s = s0 + (uint32_t)lane;
-                    u32x4 rc[CG];
-                    // unconditional loads (a clamped slot of the same cell; every cell array has at least one slot) so that
-                    // all CG loads are issued back to back; lanes past the fill count get a far-away point afterwards
-#pragma unroll
-                    for (int g = 0; g < CG; ++g) rc[g] = rec[g][s < cnt[g] ? s : 0u];  // {xy, index, vcost}
-#pragma unroll
-                    for (int g = 0; g < CG; ++g)
-                        if (!(s < cnt[g])) rc[g].x = 0x7fff7fffu;  // never within the radius
-                    bool dirty = false;
-#pragma unroll
-                    for (int g = 0; g < CG; ++g) {
-                        const uint32_t d2 = dist2(rc[g].x, X);
-                        const bool hit = d2 < r2 && (!check_j0 || rc[g].y < (uint32_t)j0);
-                        hits += hit ? 1u : 0u;
-                        // park everything whose vcost alone can be below the bound (the high word of a non-negative f64 is monotone)
-                        const bool park = hit && rc[g].w <= boundhi;
-                        const unsigned long long pm = __ballot(park);
-                        if (pm == 0) continue;
-                        if (park) {
-                            const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                            if (pos < clist_cap) clist[pos] = u32x4{rc[g].y, d2, rc[g].z, rc[g].w};
-                        }
-                        nlist += (uint32_t)__builtin_popcountll(pm);
-                        // screens, cheapest first; none rejects an entry that belongs to the two cheapest
-                        const bool pre = park && rc[g].w <= Thi;
-                        if (__ballot(pre) == 0) continue;
-                        const double V = __longlong_as_double((long long)(((unsigned long long)rc[g].w << 32) | rc[g].z));
-                        const bool maybe = pre && ((float)V + __builtin_amdgcn_sqrtf((float)d2) < T);
-                        if (__ballot(maybe) == 0) continue;
-                        if (maybe) {
-                            const double cn = V + sqrt_u24(d2);
-                            if (cn < bound && !key_lt(cn, rc[g].y, lbc, lbi)) {  // rrt.py:518, strict
-                                tt.fold(cn, rc[g].y);
-                                const float cu = screen_of(cn);
-                                if (cu < m1) {
-                                    m2 = m1;
-                                    m1 = cu;
-                                } else if (cu < m2) {
-                                    m2 = cu;
-                                }
-                            }
-                        }
-                        dirty = true;
-                    }
-                    if (dirty) {  // tighten the screen to (an upper bound of) the wave's second cheapest so far
-                        const float w1 = wave_min_f32_nonneg(m1);
-                        const float w2 = wave_min_f32_nonneg(m1 == w1 ? m2 : m1);
-                        T = w2 < boundf ? w2 : boundf;
-                        Thi = hi_of((double)T);
-                    }
-                }
-            }
-            nnear = wave_sum_u32(hits);
-            tt.wave_reduce();
+            uint32_t nlist = 0;
+            stream_cells(X, j0, check_j0, bound, lbc, lbi, 0, 1, tt, nnear, nlist);
             if (tt.i1 == NONE) return;
             // the two cheapest, both lines of sight in flight together (rrt.py:519); the second counts only if needed
             bool ok1, ok2;
@@ -391,161 +557,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             lbc = tt.c2;
             lbi = tt.i2 + 1;
             if (nlist > clist_cap) continue;  // the list overflowed: stream the cells again above the new lower bound
-            // both blocked: price the parked entries once and compact the ones still open (cost < bound, key >= lower bound) to
-            // the front of the list as {index, cells, cost}.  A sample behind a wall has dozens of cheaper-but-blocked
-            // candidates; two per memory round trip made it the straggler of its block, so the rest is tested up to 8 lines of
-            // sight at a time:
-            //   <= 16 open entries: rank them in (cost, index) order and test ranks 0-7, 8-15 (one wave per line of sight)
-            //   more: every entry is tested, one line of sight per LANE.
             uint32_t nval = 0;
-            for (uint32_t p0 = 0; p0 < nlist; p0 += 64) {
-                const uint32_t p = p0 + (uint32_t)lane;
-                u32x4 e = {NONE, 0u, 0u, 0u};
-                if (p < nlist) e = clist[p];  // {index, d2, vcost}
-                const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
-                double cn = f64_inf();
-                if (p < nlist && (float)V + __builtin_amdgcn_sqrtf((float)e.y) < boundf) {
-                    const double c = V + sqrt_u24(e.y);
-                    if (c < bound && !key_lt(c, e.x, lbc, lbi)) cn = c;
-                }
-                const bool open = cn < bound;
-                const unsigned long long om = __ballot(open);
-                if (open) {  // positions at or below the ones this iteration has read
-                    const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
-                    clist[nval + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)};
-                }
-                nval += (uint32_t)__builtin_popcountll(om);
-            }
-            if (nval == 0) return;  // every entry was tried
-            const bool batch = rad < 64;  // every near-set segment fits one 64-cell ballot
-            double wc = f64_inf();        // cheapest passing entry (only the group that ends the search can hold one)
-            uint32_t wi = NONE;
-            if (nval <= 16) {
-                u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
-                if ((uint32_t)lane < nval) e = clist[lane];
-                const unsigned long long kb = ((unsigned long long)e.w << 32) | e.z;  // non-negative doubles order like their bits
-                uint32_t rank = 0;
-                for (uint32_t jn = 0; jn < nval; ++jn) {
-                    const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)e.w, (int)jn) << 32) |
-                                                  (uint32_t)__builtin_amdgcn_readlane((int)e.z, (int)jn);
-                    const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)jn);
-                    rank += (kj < kb || (kj == kb && ij < e.x)) ? 1u : 0u;
-                }
-                const uint32_t step = batch ? (uint32_t)LOSB : 1u;
-                for (uint32_t r0 = 0; r0 < nval; r0 += step) {
-                    unsigned long long m = __ballot((uint32_t)lane < nval && rank >= r0 && rank < r0 + step);
-                    uint32_t ci[LOSB], cxy[LOSB], clo[LOSB], chi[LOSB];
-                    int nc = 0;
-#pragma unroll
-                    for (int c = 0; c < LOSB; ++c) {
-                        ci[c] = NONE;
-                        cxy[c] = X;
-                        clo[c] = 0u;
-                        chi[c] = 0x7ff00000u;
-                        if (m != 0) {
-                            const int src = (int)__builtin_ctzll(m);
-                            m &= m - 1;
-                            ci[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.x, src);
-                            clo[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.z, src);
-                            chi[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.w, src);
-                            nc = c + 1;
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < LOSB; ++c)
-                        if (c < nc) cxy[c] = node_xy(ci[c]);
-                    bool okc[LOSB];
-                    int ccs[LOSB];
-                    if (batch) {
-                        los_batch(og, H, cxy, nc, X, lane, okc, ccs);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < LOSB; ++c) {
-                            okc[c] = false;
-                            ccs[c] = 0;
-                        }
-                        okc[0] = los_wave(og, H, cxy[0], X, lane, ccs[0]);
-                    }
-#pragma unroll
-                    for (int c = 0; c < LOSB; ++c) {
-                        const double cc = __longlong_as_double((long long)(((unsigned long long)chi[c] << 32) | clo[c]));
-                        if (c < nc && okc[c] && key_lt(cc, ci[c], wc, wi)) {
-                            wc = cc;
-                            wi = ci[c];
-                        }
-                    }
-                    // statistics as the sequential loop counts them: the tests up to and including the first passing entry
-#pragma unroll
-                    for (int c = 0; c < LOSB; ++c) {
-                        const double cc = __longlong_as_double((long long)(((unsigned long long)chi[c] << 32) | clo[c]));
-                        if (c < nc && (wi == NONE || !key_lt(wc, wi, cc, ci[c]))) {
-                            ntests += 1;
-                            tcells += (uint32_t)ccs[c];
-                        }
-                    }
-                    if (wi != NONE) break;
-                }
-                pc = wc;
-                pi = wi;
-                return;
-            }
-            // many open entries: one line of sight PER LANE, 64 entries at a time, every entry tested (each lane walks its own
-            // segment, four cell loads in flight); the answer is the cheapest passing entry
-            for (uint32_t p0 = 0; p0 < nval; p0 += 64) {
-                const uint32_t p = p0 + (uint32_t)lane;
-                const bool have = p < nval;
-                u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
-                if (have) e = clist[p];
-                const uint32_t axy = have ? node_xy(e.x) : X;
-                const rrt_line_t ln = rrt_line_setup(ux(axy), uy(axy), ux(X), uy(X));
-                const int L = ln.major;
-                bool blocked = false;
-                int cells = L + 1;
-                for (int k0 = 0; __any(!blocked && k0 <= L); k0 += 4) {
-                    uint8_t v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {  // unconditional loads (clamped to the segment's last cell)
-                        const int kk = (k0 + u) < L ? (k0 + u) : L;
-                        int x, y;
-                        rrt_line_cell(&ln, kk, &x, &y);
-                        v[u] = og[(size_t)x * H + y];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (!blocked && k0 + u <= L && v[u] != 0) {
-                            blocked = true;
-                            cells = k0 + u + 1;
-                        }
-                }
-                if (have) clist[p].y = (uint32_t)cells;  // cells read by this test, for the statistics pass
-                double cn = f64_inf();
-                uint32_t ci = NONE;
-                if (have && !blocked) {
-                    cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
-                    ci = e.x;
-                }
-                wave_min_f64_idx(cn, ci);
-                if (ci != NONE && key_lt(cn, ci, wc, wi)) {
-                    wc = cn;
-                    wi = ci;
-                }
-            }
-            // statistics as the sequential loop counts them: the tests up to and including the first passing entry
-            {
-                uint32_t nt = 0, tcl = 0;
-                for (uint32_t p = (uint32_t)lane; p < nval; p += 64) {
-                    const u32x4 e = clist[p];
-                    const double cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
-                    if (wi == NONE || !key_lt(wc, wi, cn, e.x)) {
-                        nt += 1;
-                        tcl += e.y;
-                    }
-                }
-                ntests += wave_sum_u32(nt);
-                tcells += wave_sum_u32(tcl);
-            }
-            pc = wc;
-            pi = wi;
+            consume_list(X, bound, lbc, lbi, nlist, pc, pi, nval);
+            count_tests(clist, nval, pc, pi, ntests, tcells);
             return;
         }
     };
