@@ -36,9 +36,11 @@ extern "C" {
 
 #define RRT_FLAG_LOGS 1u   /* keep per-iteration logs (nearest, accept, ellipse cost, j) on the device */
 #define RRT_FLAG_SERIAL 2u /* use the one-sample-per-iteration kernel instead of the 16-sample block kernel */
-#define RRT_FLAG_NOTEAM 4u /* block kernel on ONE workgroup (CU) per query; default: a team of up to 4 CUs per query while
-                              all teams of the batch fit on the device together */
-#define RRT_FLAG_TEAM2 8u  /* teams of 2 CUs (testing) */
+#define RRT_FLAG_NOTEAM 4u /* block kernel on ONE workgroup (CU) per query.  Default: a team of up to 64 CUs per query, the
+                              largest for which all teams of the batch are resident on the device together */
+#define RRT_FLAG_TEAM_FAULT 8u /* testing: one member of every team leaves at once; the hand-offs of the others time out
+                                  and the batch must finish with one CU per query */
+#define RRT_FLAG_TEAM_MAX(g) ((uint32_t)(g) << 8) /* cap the team size at g CUs per query (g = 2, 4, ... 64; 0 = no cap) */
 
 typedef struct rrt_ctx rrt_ctx;
 typedef struct rrt_batch rrt_batch;
@@ -106,6 +108,8 @@ int rrt_batch_set_unitball(rrt_batch *b, int32_t q, const double *unitball, int3
 int rrt_batch_rearm(rrt_batch *b);  /* reset every query's tree, keep the uploaded inputs */
 int rrt_batch_launch(rrt_batch *b); /* asynchronous on the ctx stream; runs / resumes every unfinished query */
 int rrt_batch_sync(rrt_batch *b);
+/* CUs working on each query (team size; 1 after a fallback) and how often a team hand-off timed out */
+int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fallbacks);
 int rrt_batch_elapsed_ms(rrt_batch *b, float *ms); /* HIP events around the last launch's kernels */
 int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out);
 /* diagnostic builds (-DRRT_STAMPS): shader cycles wave 0 of query q spent in scan / barrier / nearest+line of sight /

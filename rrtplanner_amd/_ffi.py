@@ -25,25 +25,26 @@ ALG_STANDARD, ALG_STAR, ALG_INFORMED = 0, 1, 2
 FLAG_LOGS = 1
 FLAG_SERIAL = 2
 FLAG_NOTEAM = 4
-FLAG_TEAM2 = 8
+FLAG_TEAM_FAULT = 8
 
 
-def kernel_flags(logs=False, serial=False, team=None):
-    """flags word of rrt_plan / rrt_batch_create: team None = as many CUs per query as fit (up to 4), 1 = one CU, 2 = two."""
-    f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0)
+def kernel_flags(logs=False, serial=False, team=None, team_fault=False):
+    """flags word of rrt_plan / rrt_batch_create.  team: None = as many CUs per query as fit (up to 64), 1 = one CU,
+    2..64 = cap on the team size; team_fault = the fault-injection flag of the tests."""
+    f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_TEAM_FAULT if team_fault else 0)
     if team == 1:
         f |= FLAG_NOTEAM
-    elif team == 2:
-        f |= FLAG_TEAM2
-    elif team is not None and team != 4:
-        raise ValueError("team must be None, 1, 2 or 4")
+    elif team is not None:
+        if team not in (2, 4, 8, 16, 32, 64):
+            raise ValueError("team must be None, 1, 2, 4, 8, 16, 32 or 64")
+        f |= int(team) << 8
     return f
 
 # every symbol include/rrt_hip.h declares (tests/test_capi_symbols.py checks the library exports them)
 SYMBOLS = (
     "rrt_ctx_create", "rrt_ctx_destroy", "rrt_last_error_string", "rrt_set_grid", "rrt_noise_grids", "rrt_select_frame",
     "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
-    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_elapsed_ms",
+    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
     "rrt_plan", "rrt_plan_resume", "rrt_plan_batch",
     "rrt_prim_collisionfree", "rrt_prim_nearest_within", "rrt_prim_sqrt_u32", "rrt_prim_sqrt_u24", "rrt_prim_sqrt_f64",
@@ -105,6 +106,7 @@ def lib():
             "rrt_batch_rearm": ([vp], C.c_int),
             "rrt_batch_launch": ([vp], C.c_int),
             "rrt_batch_sync": ([vp], C.c_int),
+            "rrt_batch_team": ([vp, C.POINTER(i32), C.POINTER(i32)], C.c_int),
             "rrt_batch_elapsed_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
             "rrt_batch_get_result": ([vp, i32, C.POINTER(Result)], C.c_int),
             "rrt_batch_result_block": ([vp, C.POINTER(vp), C.POINTER(i64)], C.c_int),
@@ -223,9 +225,9 @@ class Context:
         _check(self._h, lib().rrt_select_frame(self._h, int(k)))
 
     # ---- one-shot ----
-    def plan(self, query, n, logs=False, serial=False, team=None):
+    def plan(self, query, n, logs=False, serial=False, team=None, team_fault=False):
         res = ResultArrays(n, logs)
-        flags = kernel_flags(logs, serial, team)
+        flags = kernel_flags(logs, serial, team, team_fault)
         rc = lib().rrt_plan(self._h, C.byref(query), flags, C.byref(res.c))
         _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
         return rc, res
@@ -276,10 +278,10 @@ class Context:
 class Batch:
     """Q independent queries resident on the device (rrt_batch_*)."""
 
-    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False, team=None):
+    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False, team=None, team_fault: bool = False):
         self.ctx, self.Q, self.n_cap, self.logs = ctx, int(Q), int(n_cap), logs
         self._h = C.c_void_p()
-        flags = kernel_flags(logs, serial, team)
+        flags = kernel_flags(logs, serial, team, team_fault)
         _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, flags, C.byref(self._h)))
         self._n = [0] * self.Q
 
@@ -310,6 +312,12 @@ class Batch:
 
     def sync(self):
         _check(self.ctx.handle, lib().rrt_batch_sync(self._h))
+
+    def team(self):
+        """(CUs per query, launches repeated with one CU per query after a team hand-off timed out)"""
+        g, f = C.c_int32(0), C.c_int32(0)
+        _check(self.ctx.handle, lib().rrt_batch_team(self._h, C.byref(g), C.byref(f)))
+        return g.value, f.value
 
     def elapsed_ms(self):
         ms = C.c_float(0)

@@ -48,10 +48,10 @@ constexpr int CG = 2;   // cells whose records an owner streams concurrently
 //             joins the workgroup barrier, and only then the workgroup loads.
 // All members must be resident together (the launch keeps teams x G <= CUs); every spin is bounded by a wall-clock
 // limit that fails the query (status ST_TEAM_FAIL) instead of hanging the device.
-constexpr int TEAM_MAX = 16;
-constexpr int TEAM_BYTES = 8192;                 // per query: [go | fail | state | records | arrival flags], 128-byte lines
+constexpr int TEAM_MAX = 64;
+constexpr int TEAM_BYTES = 16384;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
 constexpr int TEAM_OFF_ARRIVE = 6144, TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384, TEAM_OFF_REC = 512;
-constexpr unsigned long long TEAM_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
+constexpr unsigned long long TEAM_TIMEOUT_TICKS = 50000000ull;  // 0.5 s of the 100 MHz wall clock
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) uint32_t gu32;
@@ -153,6 +153,18 @@ __device__ __forceinline__ void block_scan_step(u32x4 quad, const uint32_t (&xs1
     }
 }
 
+// Owner phase of a sample handled by a group of waves (team members with fewer samples than waves): what each wave
+// found in its share of the cells, and what the group's leader decided.
+struct GSlot {
+    double c1, c2;        // after stream_cells: the share's two cheapest; after consume_list: c1 = its cheapest passing entry
+    uint32_t i1, i2;
+    uint32_t hits, nlist; // after stream_cells: |within| of the share, parked entries; after consume_list: nlist = open entries
+};
+struct GCtl {
+    double lbc;
+    uint32_t lbi, consume;  // consume: the two cheapest are blocked, every wave tests its own parked entries above (lbc, lbi)
+};
+
 union BlkWords {
     BlkState b;
     u64 w[5];
@@ -170,12 +182,16 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     __shared__ __attribute__((aligned(16))) unsigned long long statred[SB * 5];
     __shared__ uint32_t xq_lds[SB];
     __shared__ double newcost[SB];
+    constexpr int WPS = NWAVE / BSM;  // waves per sample in the owner phase
+    __shared__ __attribute__((aligned(16))) GSlot gslot[NWAVE];
+    __shared__ __attribute__((aligned(16))) GCtl gctl[BSM];
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     int q = (int)blockIdx.x, g = 0;  // query, team member
     if (G > 1) {
         q = (int)blockIdx.x % bv.team_qpad;  // members of one team are 8k blocks apart: dealt to the same XCD (speed only)
         g = (int)blockIdx.x / bv.team_qpad;
         if (q >= bv.Q) return;
+        if (bv.team_fault && g == 1) return;
     }
     QDesc *D = bv.desc + q;
     if (D->status != ST_RUNNING) return;
@@ -664,6 +680,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #ifdef RRT_STAMPS
         const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (WPS == 1) {
         const int sidx = g * BSM + wave;  // the sample this wave owns (waves BSM.. of a small-BSM team member idle here)
         if (wave < BSM && sidx < nb) {
             const int k = wave;
@@ -697,6 +714,160 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             wcyc_los += __builtin_amdgcn_s_memtime() - tl0;
 #endif
             if (lane == 0) {
+                BRec r;
+                r.d2s = d2s;
+                r.vs = vs;
+                r.los_s = (free_s ? 0x80000000u : 0u) | (uint32_t)cells;
+                r.flags = (bm_word >> (cell & 31)) & 1u;
+                r.Vs = Vs;
+                r.cbest = (pi != NONE) ? pc : cnear_s;
+                r.vbest = (pi != NONE) ? pi : vs;
+                r.pstat = (ntests << 20) | (tcells & 0xfffffu);
+                r.nnmask = nnmask;
+                r.rmask = rmask;
+                r.dupmask = dupmask;
+                r.nnear = nnear;
+                r.pad = 0;
+                r.pc = pc;
+                brec[sidx] = r;
+            }
+        }
+        } else {
+            // ---- a group of WPS waves per sample: every wave streams its share of the cells; the group's first wave (leader)
+            //      combines, tests lines of sight and writes the record; blocked-candidate lists are tested by all WPS waves ----
+            const int sl = wave / WPS, part = wave % WPS;
+            const int sidx = g * BSM + sl;
+            const bool act = sidx < nb, lead = part == 0;
+            const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, act ? sidx : 0);
+            uint32_t d2s = NONE, vs = NONE;
+            if (lane < NWAVE) {
+                const u32x2 v = ((RRT_LDS u32x2 *)nnx)[sl * NWAVE + lane];
+                d2s = v.x;
+                vs = v.y;
+            }
+            wave_min_key_idx(d2s, vs);
+            const double Vs = act ? vcost[vs] : 0.0;
+            const double cnear_s = Vs + sqrt_u32(d2s);
+            double pc = f64_inf();
+            uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
+            bool free_s = false;
+            int cells = 0;
+            uint32_t bm_word = 0;
+            u64 nnmask = 0, rmask = 0, dupmask = 0;
+            const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
+            uint32_t own_nlist = 0;
+            if (star) {
+                Top2 tt;
+                tt.init();
+                uint32_t hp = 0;
+                if (act) stream_cells(Xk, j0, false, cnear_s, -1.0, 0u, part, WPS, tt, hp, own_nlist);
+                if (lane == 0) {
+                    GSlot sl_;
+                    sl_.c1 = tt.c1;
+                    sl_.c2 = tt.c2;
+                    sl_.i1 = tt.i1;
+                    sl_.i2 = tt.i2;
+                    sl_.hits = hp;
+                    sl_.nlist = own_nlist;
+                    gslot[wave] = sl_;
+                }
+                __syncthreads();
+            }
+            bool consume = false;
+            double lbc = -1.0;
+            uint32_t lbi = 0;
+            if (lead && act) {
+                bm_word = bitmap[cell >> 5];
+                free_s = los_wave(og, H, node_xy(vs), Xk, lane, cells);
+                // earlier samples of this block that could interact once inserted
+                const uint32_t xo = (lane < sidx) ? xq_lds[lane] : Xk;
+                const uint32_t dk = dist2(xo, Xk);
+                nnmask = __ballot(lane < sidx && dk < d2s);
+                rmask = __ballot(lane < sidx && star && dk < r2);
+                dupmask = __ballot(lane < sidx && xo == Xk);
+                if (star) {
+                    Top2 tt;
+                    tt.init();
+                    bool overflow = false;
+#pragma unroll
+                    for (int pp = 0; pp < WPS; ++pp) {
+                        const GSlot o = gslot[sl * WPS + pp];
+                        if (o.i1 != NONE) tt.fold(o.c1, o.i1);
+                        if (o.i2 != NONE) tt.fold(o.c2, o.i2);
+                        nnear += o.hits;
+                        overflow = overflow || o.nlist > clist_cap;
+                    }
+                    if (overflow) {  // a radius far beyond the cell size: this wave resolves the sample on its own
+                        nnear = 0;
+                        snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);
+                    } else if (tt.i1 != NONE) {
+                        // the two cheapest, both lines of sight in flight together (rrt.py:519); the second counts only if needed
+                        bool ok1, ok2;
+                        int cc1, cc2;
+                        los_wave2(og, H, node_xy(tt.i1), tt.i2 != NONE ? node_xy(tt.i2) : Xk, tt.i2 != NONE, Xk, lane, ok1, cc1, ok2, cc2);
+                        ntests += 1;
+                        tcells += (uint32_t)cc1;
+                        if (ok1) {
+                            pc = tt.c1;
+                            pi = tt.i1;
+                        } else if (tt.i2 != NONE) {
+                            ntests += 1;
+                            tcells += (uint32_t)cc2;
+                            if (ok2) {
+                                pc = tt.c2;
+                                pi = tt.i2;
+                            } else {
+                                consume = true;
+                                lbc = tt.c2;
+                                lbi = tt.i2 + 1;
+                            }
+                        }
+                    }
+                }
+            }
+            if (star) {
+                if (lead && lane == 0) {
+                    GCtl c;
+                    c.lbc = lbc;
+                    c.lbi = lbi;
+                    c.consume = (act && consume) ? 1u : 0u;
+                    gctl[sl] = c;
+                }
+                __syncthreads();
+                const GCtl c = gctl[sl];
+                if (c.consume != 0u) {  // every wave of the group: its own parked entries above the lower bound
+                    double wc;
+                    uint32_t wi, nval;
+                    consume_list(Xk, cnear_s, c.lbc, c.lbi, own_nlist, wc, wi, nval);
+                    if (lane == 0) {
+                        GSlot sl_;
+                        sl_.c1 = wc;
+                        sl_.c2 = f64_inf();
+                        sl_.i1 = wi;
+                        sl_.i2 = NONE;
+                        sl_.hits = 0;
+                        sl_.nlist = nval;
+                        gslot[wave] = sl_;
+                    }
+                }
+                __syncthreads();
+                if (lead && c.consume != 0u) {  // the first passing entry of the group, and the tests the sequential loop makes
+                    uint32_t nv[WPS];
+#pragma unroll
+                    for (int pp = 0; pp < WPS; ++pp) {
+                        const GSlot o = gslot[sl * WPS + pp];
+                        nv[pp] = o.nlist;
+                        if (o.i1 != NONE && key_lt(o.c1, o.i1, pc, pi)) {
+                            pc = o.c1;
+                            pi = o.i1;
+                        }
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < WPS; ++pp)
+                        count_tests(clist_base + (size_t)(sl * WPS + pp) * (size_t)clist_cap, nv[pp], pc, pi, ntests, tcells);
+                }
+            }
+            if (lead && act && lane == 0) {
                 BRec r;
                 r.d2s = d2s;
                 r.vs = vs;

@@ -43,6 +43,7 @@ struct rrt_batch {
     int32_t blk_lds_chunks = 1; // node chunks cached in LDS by the block kernel
     size_t blk_lds_bytes = 0;
     int32_t team = 1;           // workgroups (CUs) per query of the block kernel (rrt_block.h, teams)
+    int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
     int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
     unsigned char *d_team = nullptr;  // [Q][TEAM_BYTES] sync words, state, exchanged records; zeroed before every launch
     QDesc *d_desc = nullptr;
@@ -323,14 +324,24 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     int chunks = (n_cap + 1 + CHUNK - 1) / CHUNK;
     b->use_block = !(flags & RRT_FLAG_SERIAL);
     if (b->use_block && !(flags & RRT_FLAG_NOTEAM)) {
-        // a team of 4 (2) CUs per query while every member of every team can be resident at once; teams are laid out
-        // member-major over Q rounded up to 8 so that the members of a team land on one XCD
-        b->team_qpad = (Q + 7) & ~7;
-        int want = (flags & RRT_FLAG_TEAM2) ? 2 : 16;
+        // the largest team (CUs per query) with every member of every team resident at once.  Blocks are dealt round-robin
+        // to the 8 XCDs, so block = member * stride + query with stride = 0 (mod 8) keeps a team of up to 16 on one XCD (one
+        // L2); larger teams use stride = 4 / 2 (mod 8): two / four XCDs with 16 members each.  Placement is speed only.
+        int want = (int)((flags >> 8) & 0x7fu);
+        if (want == 0) want = TEAM_MAX;
         if (const char *e = getenv("RRT_TEAM")) want = atoi(e);  // experiments: cap the team size
         b->team = 1;
-        for (int g : {2, 4, 8, 16})
-            if (g <= want && b->team_qpad * g <= ctx->num_cu) b->team = g;
+        b->team_qpad = (Q + 7) & ~7;
+        for (int g : {2, 4, 8, 16, 32, 64}) {
+            const int step = g <= 16 ? 8 : (g == 32 ? 4 : 2);
+            int stride = ((Q + step - 1) / step) * step;
+            if (g == 32 && stride % 8 == 0) stride += 4;
+            if (g == 64 && stride % 4 == 0) stride += 2;
+            if (g <= want && stride * g <= ctx->num_cu) {
+                b->team = g;
+                b->team_qpad = stride;
+            }
+        }
     }
     b->spill_stride = chunks * CHUNK * b->team;  // per member: 256 parked entries per wave and node chunk; also go2goal's cost array
     {   // block kernel LDS: [node cache | cell fill counts 16 KiB]
@@ -501,11 +512,14 @@ static BatchView make_view(rrt_batch *b) {
     v.team = b->d_team;
     v.Q = b->Q;
     v.team_qpad = b->team_qpad;
+    v.team_fault = (b->flags & RRT_FLAG_TEAM_FAULT) ? 1 : 0;
     return v;
 }
 
 static const void *block_kernel_of(int team) {
     switch (team) {
+        case 64: return reinterpret_cast<const void *>(rrt_expand_block_kernel<64, 1>);
+        case 32: return reinterpret_cast<const void *>(rrt_expand_block_kernel<32, 2>);
         case 16: return reinterpret_cast<const void *>(rrt_expand_block_kernel<16, 4>);
         case 8: return reinterpret_cast<const void *>(rrt_expand_block_kernel<8, 8>);
         case 4: return reinterpret_cast<const void *>(rrt_expand_block_kernel<4, 16>);
@@ -539,7 +553,11 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         if (b->team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
         const dim3 tg((unsigned)(b->team_qpad * b->team));
-        if (b->team == 16)
+        if (b->team == 64)
+            hipLaunchKernelGGL((rrt_expand_block_kernel<64, 1>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        else if (b->team == 32)
+            hipLaunchKernelGGL((rrt_expand_block_kernel<32, 2>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        else if (b->team == 16)
             hipLaunchKernelGGL((rrt_expand_block_kernel<16, 4>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
         else if (b->team == 8)
             hipLaunchKernelGGL((rrt_expand_block_kernel<8, 8>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
@@ -574,6 +592,30 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(b->h_desc.data(), b->d_desc, (size_t)b->Q * sizeof(QDesc), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // A team whose members were not resident together stops at a block boundary with a consistent tree (ST_TEAM_FAIL, a
+    // bounded wait expired).  Teams are only an optimisation: the batch continues from there with one CU per query.
+    bool team_fail = false;
+    for (auto &d : b->h_desc)
+        if (d.status == ST_TEAM_FAIL) {
+            d.status = ST_RUNNING;
+            team_fail = true;
+        }
+    if (team_fail && b->team > 1) {
+        b->team = 1;
+        b->team_fallbacks += 1;
+        HIPCHK(ctx, hipMemcpyAsync(b->d_desc, b->h_desc.data(), (size_t)b->Q * sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream));
+        int rc = rrt_batch_launch(b);
+        if (rc != RRT_OK) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(b->h_desc.data(), b->d_desc, (size_t)b->Q * sizeof(QDesc), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fallbacks) {
+    if (!b || !cus_per_query) return fail(nullptr, RRT_E_ARG, "rrt_batch_team: NULL");
+    *cus_per_query = b->use_block ? b->team : 1;
+    if (fallbacks) *fallbacks = b->team_fallbacks;
     return RRT_OK;
 }
 

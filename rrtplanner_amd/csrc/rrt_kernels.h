@@ -66,7 +66,8 @@ struct BatchView {
     uint32_t *cellcnt;        // [Q][MAX_CELLS]     fill counts of the cells
     int64_t rec_stride;
     unsigned char *team;      // [Q][TEAM_BYTES]    block kernel with teams: sync words, state, exchanged records
-    int32_t Q, team_qpad;     // queries of the batch; Q rounded up to a multiple of 8 (block = member * team_qpad + query)
+    int32_t Q, team_qpad;     // queries of the batch; block stride between the members of a team (block = member * team_qpad + query)
+    int32_t team_fault;       // testing: member 1 of every team leaves at once (the others' hand-offs time out)
 };
 
 constexpr int MAX_CELLS = 4096;  // cells per query (their fill counts live in LDS: 16 KiB)

@@ -143,8 +143,12 @@ def test_replan_chain_rng_continues_and_set_og(tag):
 
 
 # ------------------------------------------------------------------------------- device vs oracle, larger
-KERNELS = ["team", "team2", "block", "serial"]  # 4 CUs per query (default), 2 CUs, 1 CU, one sample per iteration
-_KERNEL_ARGS = {"team": {}, "team2": {"team": 2}, "block": {"team": 1}, "serial": {"serial": True}}
+# teams of up to 64 CUs per query (default), capped teams (2 and 4: 16 samples per member; 16: 4 samples per member, 4 waves
+# per sample), one CU, one sample per iteration, and a team that loses a member (must finish on one CU per query)
+KERNELS = ["team", "team2", "team4", "team16", "block", "serial", "teamfault"]
+KERNELS_NOFAULT = [k for k in KERNELS if k != "teamfault"]
+_KERNEL_ARGS = {"team": {}, "team2": {"team": 2}, "team4": {"team": 4}, "team16": {"team": 16}, "block": {"team": 1},
+                "serial": {"serial": True}, "teamfault": {"team": 8, "team_fault": True}}
 
 
 def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None, kernel="team"):
@@ -187,7 +191,7 @@ def test_device_vs_oracle_1024_n6000(gpu_ctx, alg, rr, rg, kernel):
     _oracle_vs_device(gpu_ctx, og8, alg, 6000, 0, xs, xg, rr, rg, kernel=kernel)
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_NOFAULT)
 def test_device_vs_oracle_beyond_lds_capacity(gpu_ctx, kernel):
     """n = 40000 exceeds the LDS-resident node chunks: the scan crosses from LDS chunks into HBM chunks."""
     og = perlin_occupancygrid(1024, 1024, seed=1)
@@ -197,7 +201,7 @@ def test_device_vs_oracle_beyond_lds_capacity(gpu_ctx, kernel):
     _oracle_vs_device(gpu_ctx, og8, 1, 40000, 0, xs, xg, 64, None, kernel=kernel)
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_NOFAULT)
 def test_device_vs_oracle_near_set_spills(gpu_ctx, kernel):
     """r_rewire far beyond the grid: the near set is the whole tree and overflows the LDS lists."""
     og = perlin_occupancygrid(256, 256, seed=4)
@@ -222,7 +226,7 @@ def test_device_vs_oracle_dense_interactions(gpu_ctx, alg, rr, rg, grid, n, seed
     _oracle_vs_device(gpu_ctx, og8, alg, n, seed, xs, xg, rr, rg, kernel=kernel)
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_NOFAULT)
 def test_device_vs_oracle_2048_grid(gpu_ctx, kernel):
     """The largest supported grid (BASELINE config 5's size): squared distances use all 23 key bits."""
     og = perlin_occupancygrid(2048, 2048, seed=3)
@@ -233,7 +237,7 @@ def test_device_vs_oracle_2048_grid(gpu_ctx, kernel):
     _oracle_vs_device(gpu_ctx, og8, 2, 12000, 6, (3, 2044), (2040, 5), 200.5, 40, kernel=kernel) if og8[3, 2044] == 0 and og8[2040, 5] == 0 else None
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_NOFAULT)
 def test_fuzz_small_queries_vs_oracle(gpu_ctx, kernel):
     """600 random small queries (grids 8..70 cells wide, n up to 700, radii from 0 to beyond the grid, all three planners, starts
     on obstacles, n larger than the free space) -- every block-cut / capacity / duplicate / interaction path of the kernels."""
@@ -292,6 +296,39 @@ def test_batch_of_queries_matches_single_queries(gpu_ctx):
             assert np.array_equal(res.parent[:live], ro.parent[:live])
             assert np.array_equal(res.vcost[:live], ro.vcost[:live])
         b.rearm()
+    b.close()
+
+
+def test_team_that_loses_a_member_finishes_on_one_cu_per_query(gpu_ctx):
+    """RRT_FLAG_TEAM_FAULT: member 1 of every team leaves at once, so a hand-off of the others times out (bounded wait); the
+    batch must notice, continue from the consistent block boundary with one CU per query, and give the oracle's trees."""
+    og = perlin_occupancygrid(512, 512, seed=4)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    sg = np.random.default_rng(11)
+    Q, n = 3, 2500
+    b = _ffi.Batch(gpu_ctx, Q, n, team=8, team_fault=True)
+    assert b.team() == (8, 0)
+    keep, refs = [], []
+    for q in range(Q):
+        xs, xg = random_connected_pair(og, sg)
+        samples = hostprep.draw_free_samples(np.random.default_rng(100 + q), free, n)
+        qu, k = _ffi.make_query(1, n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(40))
+        keep.append(k)
+        b.set_query(q, qu)
+        refs.append(oracle.plan(og8, n, 1, xs, xg, samples, r2_rewire=hostprep.radius_threshold(40)))
+    b.launch()
+    b.sync()
+    assert b.team() == (1, 1)
+    for q in range(Q):
+        res = b.get_result(q)
+        st, ro = refs[q]
+        live = ro.j + (1 if ro.found else 0)
+        assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal
+        assert np.array_equal(res.pts[:live], ro.pts[:live])
+        assert np.array_equal(res.parent[:live], ro.parent[:live])
+        assert np.array_equal(res.vcost[:live], ro.vcost[:live])
     b.close()
 
 
