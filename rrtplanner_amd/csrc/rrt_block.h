@@ -851,20 +851,36 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     }
                 }
                 __syncthreads();
-                if (lead && c.consume != 0u) {  // the first passing entry of the group, and the tests the sequential loop makes
-                    uint32_t nv[WPS];
-#pragma unroll
-                    for (int pp = 0; pp < WPS; ++pp) {
-                        const GSlot o = gslot[sl * WPS + pp];
-                        nv[pp] = o.nlist;
-                        if (o.i1 != NONE && key_lt(o.c1, o.i1, pc, pi)) {
-                            pc = o.c1;
-                            pi = o.i1;
-                        }
+                if (c.consume != 0u) {
+                    // every wave: the first passing entry of the group (lane pp < WPS reads share pp's), then the tests the
+                    // sequential loop makes over its own entries; the leader adds the counts up behind one more barrier
+                    double gc = f64_inf();
+                    uint32_t gi = NONE;
+                    if (lane < WPS) {
+                        gc = gslot[sl * WPS + lane].c1;
+                        gi = gslot[sl * WPS + lane].i1;
                     }
-#pragma unroll
-                    for (int pp = 0; pp < WPS; ++pp)
-                        count_tests(clist_base + (size_t)(sl * WPS + pp) * (size_t)clist_cap, nv[pp], pc, pi, ntests, tcells);
+                    wave_min_f64_idx(gc, gi);
+                    uint32_t nt = 0, tcl = 0;
+                    count_tests(clist, gslot[wave].nlist, gc, gi, nt, tcl);
+                    if (lane == 0) {
+                        gslot[wave].hits = nt;
+                        gslot[wave].i2 = tcl;
+                    }
+                    if (lead) {
+                        pc = gc;
+                        pi = gi;
+                    }
+                }
+                __syncthreads();
+                if (lead && c.consume != 0u) {
+                    uint32_t nt = 0, tcl = 0;
+                    if (lane < WPS) {
+                        nt = gslot[sl * WPS + lane].hits;
+                        tcl = gslot[sl * WPS + lane].i2;
+                    }
+                    ntests += wave_sum_u32(nt);
+                    tcells += wave_sum_u32(tcl);
                 }
             }
             if (lead && act && lane == 0) {
