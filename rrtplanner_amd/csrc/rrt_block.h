@@ -975,29 +975,33 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             int cur = 0;
             bool cut = false;
             if (lane < nb) newcost[lane] = r.cbest;  // optimistic (snapshot-resolved) cost; exact once the sample has committed
+            // harm: the earlier samples within r_rewire that, once inserted at their cost, would be tried as this sample's parent
+            // before the snapshot's choice: cost-through-it < cost through the snapshot parent (ties go to the lower index = the
+            // snapshot, rrt.py:518-521).  A single-precision bound settles almost every pair; bit k is re-evaluated when sample
+            // k's cost becomes exact.
+            auto harmful = [&](int kk) -> bool {
+                const uint32_t d2 = dist2(xq_lds[kk], xv);
+                const double nc = newcost[kk];
+                const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
+                if (low >= screen_of(r.cbest)) return false;
+                return nc + sqrt_u32(d2) < r.cbest;
+            };
+            u64 harm = 0;
+            if (lane < nb && acc0) {
+                u64 rm = r.rmask;
+                while (rm) {
+                    const int kk = __builtin_ctzll(rm);
+                    rm &= rm - 1;
+                    if (harmful(kk)) harm |= 1ull << kk;
+                }
+            }
             while (cur < nb && !cut) {
                 // ---- the run of samples [cur, k0) that commit together ----
                 const u64 pend = __ballot(acc0 && lane >= cur);
                 const u64 Aopt = acc_exact | (pend & ltmask);  // exact below cur, optimistic in [cur, lane)
                 // A sample keeps its snapshot result unless an earlier inserted sample of the block is nearer than its nearest,
-                // sits on its cell, or (accepted samples only) would be tried as a parent before the snapshot's choice:
-                // cost-through-it < cost through the snapshot parent (ties go to the lower index = the snapshot, rrt.py:518-521).
-                bool slow = false;
-                if (lane >= cur && lane < nb) {
-                    if (((r.nnmask | r.dupmask) & Aopt) != 0 || (goalhit && acc0)) {
-                        slow = true;
-                    } else if (acc0) {
-                        u64 rm = r.rmask & Aopt;
-                        while (rm) {
-                            const int kk = __builtin_ctzll(rm);
-                            rm &= rm - 1;
-                            if (newcost[kk] + sqrt_u32(dist2(xq_lds[kk], xv)) < r.cbest) {
-                                slow = true;
-                                break;
-                            }
-                        }
-                    }
-                }
+                // sits on its cell, or (accepted samples only) is a harmful candidate parent.
+                const bool slow = lane >= cur && lane < nb && (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || (goalhit && acc0));
                 const unsigned long long bad = __ballot(slow);
                 int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
                 {
@@ -1176,6 +1180,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         }
                         acc_exact |= 1ull << k;
                         j++;
+                        const bool redo = lane > k && lane < nb && acc0 && ((r.rmask >> k) & 1ull) != 0;  // its cost is exact now
+                        if (__ballot(redo) != 0 && redo) harm = (harm & ~(1ull << k)) | (harmful(k) ? (1ull << k) : 0ull);
                     }
                     cur = k + 1;
                 }
