@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--queries", type=int, default=None, help="queries per GPU (default: the config's)")
     ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--team", type=int, default=None, choices=[1, 2, 4, 8, 16, 32, 64],
+                    help="cap on the CUs per query (default: the largest team for which all teams are resident together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the informational batched leg (configs[3] share of one GPU)")
     args = ap.parse_args()
@@ -102,7 +104,7 @@ def main():
 
     ctx = _ffi.Context(local_rank)
     ctx.set_grid(og8)
-    batch = _ffi.Batch(ctx, Q, n)
+    batch = _ffi.Batch(ctx, Q, n, team=args.team)
     keep, rngs, states = [], [], []
     for slot in range(Q):
         g = rank + world * slot
@@ -207,7 +209,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {cfg['name']}", "queries_per_gpu": Q, "n": n,
                        "grid": [cfg["grid"], cfg["grid"]], "free_fraction": float((og == 0).mean()),
-                       "iters_per_s": iters_total * args.steps / dt, "unfinished_queries": nbad},
+                       "iters_per_s": iters_total * args.steps / dt, "unfinished_queries": nbad,
+                       "cus_per_query": batch.team()[0], "team_fallbacks": batch.team()[1]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "rrt_expand_block_kernel", "kernel_ms": kern_avg_ms, "algorithmic_bytes_per_launch": int(bytes_local)},
@@ -246,8 +249,8 @@ def measured_traffic(config, Q, n):
 
 
 def batched_leg(ctx, og, free, _ffi, hostprep):
-    """Informational: one GPU's share of BASELINE.json configs[3] (64 independent RRT* queries, n = 20000), one query per
-    workgroup.  Not the headline value."""
+    """Informational: one GPU's share of BASELINE.json configs[3] (64 independent RRT* queries, n = 20000), every query on
+    its own team of CUs.  Not the headline value."""
     from rrtplanner_amd.oggen import random_connected_pair
 
     cfg = CONFIGS[4]
@@ -270,10 +273,11 @@ def batched_leg(ctx, og, free, _ffi, hostprep):
     res = [b.get_result(q, arrays=False) for q in range(Q)]
     nodes = sum(r.c.j - 1 for r in res)
     by = sum(algorithmic_bytes(r.c) for r in res)
+    cus, fallbacks = b.team()
     b.close()
     ach = by / (kms / steps * 1e-3) / 1e9
     return {"workload": "BASELINE.json configs[3] share of one GPU: " + cfg["name"], "value": nodes * steps / dt, "unit": "nodes/s",
-            "ms_per_step": dt / steps * 1e3, "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "ms_per_step": dt / steps * 1e3, "cus_per_query": cus, "team_fallbacks": fallbacks, "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                           "frac": ach / HBM_PEAK_GBS, "kernel_ms": kms / steps}}
 
 

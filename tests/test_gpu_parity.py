@@ -201,6 +201,17 @@ def test_device_vs_oracle_beyond_lds_capacity(gpu_ctx, kernel):
     _oracle_vs_device(gpu_ctx, og8, 1, 40000, 0, xs, xg, 64, None, kernel=kernel)
 
 
+@pytest.mark.parametrize("kernel", ["team", "block"])
+def test_device_vs_oracle_informed_1024_n25000(gpu_ctx, kernel):
+    """Informed RRT* well into the ellipse phase (dense near sets, blocks cut where the ellipse shrinks), BASELINE config 3's grid."""
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    xs, xg = random_connected_pair(og, np.random.default_rng(7))
+    res, ro = _oracle_vs_device(gpu_ctx, og8, 2, 25000, 0, xs, xg, 64, 12, kernel=kernel)
+    assert res.i_switch < 25000  # the ellipse phase was reached
+
+
 @pytest.mark.parametrize("kernel", KERNELS_NOFAULT)
 def test_device_vs_oracle_near_set_spills(gpu_ctx, kernel):
     """r_rewire far beyond the grid: the near set is the whole tree and overflows the LDS lists."""
