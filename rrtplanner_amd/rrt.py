@@ -64,8 +64,19 @@ class RRT(object):
 
     # ------------------------------------------------------------------ graph helpers
     def route2gv(self, T: nx.DiGraph, gv) -> List[int]:
-        """Vertices of the shortest path root -> gv (reference rrt.py:87-107)."""
-        return nx.shortest_path(T, source=0, target=gv, weight="dist")
+        """Vertices of the shortest path root -> gv (reference rrt.py:87-107: Dijkstra on `dist`).
+
+        In the tree `plan()` returns every vertex has one parent, so the shortest path is the unique root path and is read
+        off the parent pointers; any other graph goes through networkx like the reference."""
+        path, v, pred = [gv], gv, T.pred
+        while v != 0:
+            ps = pred[v] if v in pred else ()
+            if len(ps) != 1 or len(path) > len(pred):
+                return nx.shortest_path(T, source=0, target=gv, weight="dist")  # not our tree (or unreachable: raises like the reference)
+            (v,) = ps
+            path.append(v)
+        path.reverse()
+        return path
 
     def vertices_as_ndarray(self, T: nx.DiGraph, path: list) -> np.ndarray:
         """(M-1, 2, 2) array of consecutive path segment endpoints (reference rrt.py:109-129)."""

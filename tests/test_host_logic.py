@@ -155,3 +155,24 @@ def test_build_graph_equals_call_by_call_construction():
         assert T.pred[v][u] is T.succ[u][v]
     assert nx.shortest_path(T, 0, vgoal, weight="dist") == nx.shortest_path(R, 0, vgoal, weight="dist")
     assert T.number_of_edges() == R.number_of_edges() and T.in_degree(vgoal) == R.in_degree(vgoal)
+
+
+def test_route2gv_parent_walk_equals_dijkstra():
+    """route2gv reads the unique root path off the parent pointers of a planner tree and must agree with the reference's
+    Dijkstra (rrt.py:87-107); a graph that is not such a tree goes through networkx."""
+    import networkx as nx
+
+    rng = np.random.default_rng(3)
+    T = nx.DiGraph()
+    n = 400
+    for v in range(n):
+        T.add_node(v, pt=rng.integers(0, 50, 2))
+    for v in range(1, n - 20):  # the last 20 vertices stay isolated like the reference's sentinel rows
+        T.add_edge(int(rng.integers(0, v)), v, dist=float(rng.random()), cost=0.0)
+    p = amd.RRTStandard.__new__(amd.RRTStandard)
+    for gv in (0, 1, 17, n - 21):
+        assert p.route2gv(T, gv) == nx.shortest_path(T, source=0, target=gv, weight="dist")
+    with pytest.raises(nx.NetworkXNoPath):
+        p.route2gv(T, n - 1)
+    T.add_edge(3, 17, dist=1e-9, cost=0.0)  # a second parent: no longer a tree
+    assert p.route2gv(T, 17) == nx.shortest_path(T, source=0, target=17, weight="dist")
