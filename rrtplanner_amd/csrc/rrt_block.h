@@ -1,30 +1,28 @@
-// rrt_block.h -- block-parallel tree expansion: 16 samples per pass of the node array.
+// rrt_block.h -- block-parallel tree expansion: up to 64 samples per pass of the node array, on 1 to 64 CUs per query.
 //
-// The sample stream of RRTStandard / RRTStar does not depend on the tree (rrt.py:240), so a block
-// of BS = 16 consecutive samples is evaluated against the tree as it stood at the start of the
-// block (the snapshot, nodes [0, j0)), and the few dependencies between samples of one block are
-// resolved afterwards in sample order.  The result is bit-identical to the sequential loop.
+// The sample stream of RRTStandard / RRTStar does not depend on the tree (rrt.py:240), so a (super-)block of consecutive
+// samples is evaluated against the tree as it stood at the start of the block (the snapshot, nodes [0, j0)), and the few
+// dependencies between samples of one block are resolved afterwards in sample order.  The result is bit-identical to the
+// sequential loop.  A team of G workgroups (one per CU) shares the block: member g takes BSM samples (see "teams" below).
 //
-//   A  scan (all 16 waves): every lane loads 4 nodes (16 bytes) once and evaluates them against the
-//      16 samples held in scalar registers: coordinates pre-scaled by 16 make
-//      v_dot2_i32_i16(d, d, tag) = 256*d2 + tag the packed nearest-neighbour key in ONE instruction
-//      (brute force over the whole live tree, near :150-155).
+//   A  scan (all 16 waves of every member): every lane loads 4 nodes (16 bytes) once and evaluates them against the member's
+//      samples held in scalar registers: coordinates pre-scaled by 16 make v_dot2_i32_i16(d, d, tag) = 256*d2 + tag the packed
+//      nearest-neighbour key in ONE instruction (brute force over the whole live tree, near :150-155).
 //      -- barrier --
-//   B  owner phase: wave k owns sample k.  It folds the 16 per-wave minima (lowest index on ties),
-//      tests the line of sight snapshot-nearest -> sample and reads the `sampled` bit (rrt.py:424-425).
-//      RRT*: the radius-ball near set (within :176-181) comes from a uniform cell grid over the map:
-//      every tree node also lives as a 16-byte record {xy, index, vcost} in the array of its cell, so
-//      the owner streams the records of the cells the ball touches (coalesced 16-byte loads, no
-//      gathers), prices them (vcost + sqrt(d2)) and finds the first entry in (cost, index) order with
-//      cost < cost-via-nearest and a free line of sight (choose parent :511-521).  vcost never changes
-//      after the insert (the rewire predicate :536 is never true), so the copy in the record stays valid.
-//      -- barrier --
-//   C  commit (wave 0): samples whose result cannot be changed by an earlier sample of the same block
-//      (none inserted that is nearer than the snapshot nearest, within r_rewire, or on the same cell)
-//      commit together, lane-parallel; a sample that can is re-resolved against snapshot + inserted
-//      block nodes on its own, in order.  An Informed block is cut where the ellipse changes
+//   B  owner phase: one wave (or a group of 2..16 waves) per sample.  It folds the 16 per-wave minima (lowest index on
+//      ties), tests the line of sight snapshot-nearest -> sample and reads the `sampled` bit (rrt.py:424-425).
+//      RRT*: the radius-ball near set (within :176-181) comes from a uniform cell grid over the map: every tree node also
+//      lives as a 16-byte record {xy, index, vcost} in the array of its cell, so the owners stream the records of the cells
+//      the ball touches (coalesced 16-byte loads, no gathers), price them (vcost + sqrt(d2)) and find the first entry in
+//      (cost, index) order with cost < cost-via-nearest and a free line of sight (choose parent :511-521).  vcost never
+//      changes after the insert (the rewire predicate :536 is never true), so the copy in the record stays valid.
+//      -- barrier; members g > 0 hand their records to member 0 --
+//   C  commit (wave 0 of member 0, one lane per sample): samples whose result cannot be changed by an earlier sample of the
+//      same block (none inserted that is nearer than the snapshot nearest, on the same cell, or a candidate parent that
+//      would be tried before the snapshot's choice) commit together, lane-parallel; a sample that can is re-resolved against
+//      snapshot + inserted block nodes on its own, in order.  An Informed block is cut where the ellipse changes
 //      (rrt.py:698-700, :744-745).
-//      -- barrier --
+//      -- member 0 publishes the new state; barrier --
 #pragma once
 
 #include "rrt_kernels.h"
