@@ -21,7 +21,108 @@ from tqdm import tqdm
 from . import _ffi, hostprep
 from .hostprep import INT64_MIN
 
-__all__ = ["r2norm", "random_point_og", "RRT", "RRTStandard", "RRTStar", "RRTStarInformed"]
+__all__ = ["r2norm", "random_point_og", "RRT", "RRTStandard", "RRTStar", "RRTStarInformed", "TreeDiGraph"]
+
+
+def _fill_graph(T, vgoal, points, parents, vcosts):
+    """Fill the node / adjacency dictionaries of DiGraph `T` like build_graph of the reference (rrt.py:357-369): node order
+    [vgoal, 0, 1, ...], one edge per tree link in the order of `parents`, attributes `pt` (int64 row view), `dist` (float),
+    `cost` (np.float64).  The dictionaries are written directly (same dict-of-dict layout `add_node` / `add_edge` produce, one
+    shared attribute dict per edge in `_succ` and `_pred`), ~3x faster than 100 000 add_node / add_edge calls;
+    tests/test_host_logic.py compares it with the call-by-call construction."""
+    rows = len(points)
+    order = [vgoal] + [i for i in range(rows) if i != vgoal] if 0 <= vgoal < rows else [vgoal] + list(range(rows))
+    pts = list(points)  # row views, like `for i, p in enumerate(points)`
+    node, succ, pred = T._node, T._succ, T._pred
+    for v in order:
+        node[v] = {"pt": pts[v]}
+        succ[v] = {}
+        pred[v] = {}
+    kids = [c for c, p in parents.items() if p is not None]
+    if kids:
+        ch = np.asarray(kids, dtype=np.int64)
+        pa = np.asarray([parents[c] for c in kids], dtype=np.int64)
+        d = points[ch] - points[pa]
+        dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64)).tolist()
+        for p, c, dd, cc in zip(pa.tolist(), kids, dist, vcosts[ch]):
+            e = {"dist": dd, "cost": cc}
+            succ[p][c] = e
+            pred[c][p] = e
+
+
+class TreeDiGraph(nx.DiGraph):
+    """The nx.DiGraph that plan() returns, with its dictionaries filled on first use.
+
+    At n = 50 000 building 100 000 Python dictionaries takes four times as long as the whole expansion on the device, and
+    the usual next calls (route2gv, vertices_as_ndarray) only need the parent pointers and the coordinates.  The instance
+    therefore keeps the result arrays and materialises `_node` / `_adj` / `_succ` / `_pred` when anything first touches
+    them; from then on it is an ordinary DiGraph with exactly the content build_graph gives (tests compare both)."""
+
+    def __init__(self, incoming_graph_data=None, **attr):
+        self.__dict__["_lazy"] = None
+        super().__init__(incoming_graph_data, **attr)
+
+    @classmethod
+    def from_arrays(cls, vgoal, points, parent, vcosts):
+        """points (rows, 2) int64, parent (live,) int (-1 for the root), vcosts (rows,) float64; rows >= live"""
+        T = cls()
+        T.__dict__["_lazy"] = (int(vgoal), points, parent, vcosts)
+        return T
+
+    def _materialise(self):
+        lazy = self.__dict__.get("_lazy")
+        if lazy is not None:
+            self.__dict__["_lazy"] = None
+            vgoal, points, parent, vcosts = lazy
+            parents = {0: None}
+            par = parent.tolist()
+            for child in range(1, len(par)):
+                parents[child] = par[child]
+            _fill_graph(self, vgoal, points, parents, vcosts)
+
+    def root_path(self, gv):
+        """[0, ..., gv] from the parent array while the graph is still lazy, else None"""
+        lazy = self.__dict__.get("_lazy")
+        if lazy is None:
+            return None
+        parent = lazy[2]
+        gv = int(gv)
+        if not 0 <= gv < len(parent):
+            return None
+        path, v = [gv], gv
+        while v != 0:
+            v = int(parent[v])
+            if v < 0 or len(path) > len(parent):
+                return None
+            path.append(v)
+        path.reverse()
+        return path
+
+    def lazy_points(self):
+        lazy = self.__dict__.get("_lazy")
+        return None if lazy is None else lazy[1]
+
+
+def _lazy_dict(name, aliases=()):
+    """Data descriptor for one of DiGraph's dictionaries: reading it materialises a lazy tree first.  (networkx keeps `_succ`
+    as an alias of `_adj`, set together; both names are served from the same slot.)"""
+    keys = ("_td" + name,) + tuple("_td" + a for a in aliases)
+
+    def get(self):
+        self._materialise()
+        return self.__dict__[keys[0]]
+
+    def set_(self, value):
+        for k in keys:
+            self.__dict__[k] = value
+
+    return property(get, set_)
+
+
+TreeDiGraph._node = _lazy_dict("_node")
+TreeDiGraph._pred = _lazy_dict("_pred")
+TreeDiGraph._adj = _lazy_dict("_adj", aliases=("_succ",))
+TreeDiGraph._succ = _lazy_dict("_succ", aliases=("_adj",))
 
 
 def r2norm(x) -> float:
@@ -68,6 +169,10 @@ class RRT(object):
 
         In the tree `plan()` returns every vertex has one parent, so the shortest path is the unique root path and is read
         off the parent pointers; any other graph goes through networkx like the reference."""
+        if isinstance(T, TreeDiGraph):
+            fast = T.root_path(gv)
+            if fast is not None:
+                return fast
         path, v, pred = [gv], gv, T.pred
         while v != 0:
             ps = pred[v] if v in pred else ()
@@ -80,7 +185,8 @@ class RRT(object):
 
     def vertices_as_ndarray(self, T: nx.DiGraph, path: list) -> np.ndarray:
         """(M-1, 2, 2) array of consecutive path segment endpoints (reference rrt.py:109-129)."""
-        pts = [T.nodes[v]["pt"] for v in path]
+        lazy_pts = T.lazy_points() if isinstance(T, TreeDiGraph) else None
+        pts = [lazy_pts[v] for v in path] if lazy_pts is not None else [T.nodes[v]["pt"] for v in path]
         return np.array([[pts[k], pts[k + 1]] for k in range(len(path) - 1)])
 
     # ------------------------------------------------------------------ static primitives
@@ -229,39 +335,16 @@ class RRT(object):
         if found:
             points[n] = res.xg
             vcosts[n] = vcosts[vgoal]
-        parents = {0: None}
-        par = res.parent[:live].tolist()
-        for child in range(1, live):
-            parents[child] = par[child]
-        return self.build_graph(vgoal, points, parents, vcosts), vgoal
+        return TreeDiGraph.from_arrays(vgoal, points, np.array(res.parent[:live], dtype=np.int64), vcosts), vgoal
 
     def build_graph(self, vgoal, points, parents, vcosts) -> nx.DiGraph:
         """DiGraph with every row of `points` as a node (`pt`) and one edge per tree link with
         `dist` (float) and `cost` (np.float64) -- node order [vgoal, 0, 1, ...] and edge order of the
         `parents` dict, as reference rrt.py:357-369.
 
-        The adjacency dicts are filled directly (same dict-of-dict layout `add_node` / `add_edge` produce, same
-        insertion order, one shared attribute dict per edge in `_succ` and `_pred`), which is ~3x faster than
-        50 000 `add_edge` calls; tests/test_host_logic.py compares it with the call-by-call construction."""
+        (The tree plan() returns is a TreeDiGraph, which fills the same dictionaries on first use.)"""
         T = nx.DiGraph()
-        rows = len(points)
-        order = [vgoal] + [i for i in range(rows) if i != vgoal] if 0 <= vgoal < rows else [vgoal] + list(range(rows))
-        pts = list(points)  # row views, like `for i, p in enumerate(points)`
-        node, succ, pred = T._node, T._succ, T._pred
-        for v in order:
-            node[v] = {"pt": pts[v]}
-            succ[v] = {}
-            pred[v] = {}
-        kids = [c for c, p in parents.items() if p is not None]
-        if kids:
-            ch = np.asarray(kids, dtype=np.int64)
-            pa = np.asarray([parents[c] for c in kids], dtype=np.int64)
-            d = points[ch] - points[pa]
-            dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64)).tolist()
-            for p, c, dd, cc in zip(pa.tolist(), kids, dist, vcosts[ch]):
-                e = {"dist": dd, "cost": cc}
-                succ[p][c] = e
-                pred[c][p] = e
+        _fill_graph(T, vgoal, points, parents, vcosts)
         return T
 
     def _plan(self, alg, xstart, xgoal, **kw):

@@ -176,3 +176,40 @@ def test_route2gv_parent_walk_equals_dijkstra():
         p.route2gv(T, n - 1)
     T.add_edge(3, 17, dist=1e-9, cost=0.0)  # a second parent: no longer a tree
     assert p.route2gv(T, 17) == nx.shortest_path(T, source=0, target=17, weight="dist")
+
+
+def test_tree_digraph_is_lazy_and_equal_to_build_graph():
+    """plan() returns a TreeDiGraph: route2gv / vertices_as_ndarray work from the result arrays, and the first touch of the
+    graph itself fills exactly what build_graph (reference rrt.py:334-369) builds."""
+    import pickle
+
+    import networkx as nx
+
+    rng = np.random.default_rng(5)
+    n, live = 300, 260
+    points = np.full((n + 1, 2), hostprep.INT64_MIN, dtype=np.int64)
+    points[:live] = rng.integers(0, 90, (live, 2))
+    points[n] = points[7]
+    vcosts = np.full(n + 1, np.inf)
+    vcosts[:live] = rng.random(live)
+    vcosts[n] = vcosts[7]
+    parent = np.array([-1] + [int(rng.integers(0, c)) for c in range(1, live)], dtype=np.int64)
+    vgoal = live - 1
+    p = amd.RRTStandard.__new__(amd.RRTStandard)
+    T = amd.TreeDiGraph.from_arrays(vgoal, points, parent, vcosts)
+    assert isinstance(T, nx.DiGraph) and T.lazy_points() is not None
+    path = p.route2gv(T, vgoal)
+    segs = p.vertices_as_ndarray(T, path)
+    assert T.lazy_points() is not None  # still only arrays
+    ref = p.build_graph(vgoal, points, {0: None, **{c: int(parent[c]) for c in range(1, live)}}, vcosts)
+    assert path == nx.shortest_path(ref, 0, vgoal, weight="dist")
+    assert np.array_equal(segs, np.array([[points[a], points[b]] for a, b in zip(path[:-1], path[1:])]))
+    T2 = pickle.loads(pickle.dumps(T))  # lazy state survives pickling
+    assert T.number_of_nodes() == ref.number_of_nodes() and T.lazy_points() is None
+    for G in (T, T2, T.copy()):
+        assert list(G.nodes) == list(ref.nodes) and list(G.edges) == list(ref.edges)
+        assert all(G.edges[e] == ref.edges[e] for e in ref.edges)
+        assert all(np.array_equal(G.nodes[v]["pt"], ref.nodes[v]["pt"]) for v in ref.nodes)
+    assert p.route2gv(T, vgoal) == path  # and after materialisation
+    T.add_edge(3, 9999, dist=1.0)  # an ordinary DiGraph from here on
+    assert T.has_edge(3, 9999)
