@@ -197,6 +197,12 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     gu32 *const t_arrive = (gu32 *)(tb + TEAM_OFF_ARRIVE), *const t_go = (gu32 *)(tb + TEAM_OFF_GO), *const t_fail = (gu32 *)(tb + TEAM_OFF_FAIL);
     gu64 *const t_state = (gu64 *)(tb + TEAM_OFF_STATE), *const t_rec = (gu64 *)(tb + TEAM_OFF_REC);
     uint32_t epoch = 0;  // super-blocks of this launch so far
+    // pre-scan (team members, RRTStandard / RRTStar): while member 0 commits block s, a member already scans the snapshot of
+    // block s for the samples of block s + 1; after the commit only the steps that hold the new nodes are scanned again
+    int pre_i = -1, pre_j = 0;  // the iteration the pre-scan is for, the node count it covered
+    uint32_t pre_xv = 0, pre_best[BSM];
+#pragma unroll
+    for (int k = 0; k < BSM; ++k) pre_best[k] = NONE;
     bool team_failed = false;
 
     // ---- per-query views ----
@@ -578,6 +584,30 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         }
     };
 
+    // steps [c0, c1) of the scan: 4096 nodes per step, from the LDS cache or (beyond it) from HBM, next step prefetched
+    auto scan_steps = [&](int c0, int c1, const uint32_t (&xs16)[BSM], uint32_t (&best)[BSM]) {
+        const int nl = c1 < lds_chunks ? c1 : lds_chunks;
+        if (c0 < nl) {
+            u32x4 cur = nodes_lds4[c0 * TPB + t];
+            for (int c = c0; c < nl; ++c) {
+                u32x4 nxt = cur;
+                if (c + 1 < nl) nxt = nodes_lds4[(c + 1) * TPB + t];
+                block_scan_step<BSM>(cur, xs16, best, (uint32_t)c << 2);
+                cur = nxt;
+            }
+        }
+        const int g0 = c0 > nl ? c0 : nl;
+        if (c1 > g0) {
+            u32x4 cur = nodes_g4[g0 * TPB + t];
+            for (int c = g0; c < c1; ++c) {
+                u32x4 nxt = cur;
+                if (c + 1 < c1) nxt = nodes_g4[(c + 1) * TPB + t];
+                block_scan_step<BSM>(cur, xs16, best, (uint32_t)c << 2);
+                cur = nxt;
+            }
+        }
+    };
+
     while (i < n) {
         const int i0 = i, j0 = j;
         const int nb = (n - i0) < SB ? (n - i0) : SB;  // samples of this (super-)block; lane s of every wave: sample s
@@ -608,7 +638,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 vy = (vy > 0.0) ? vy : 0.0;
                 xv = pack_xy((int)vx, (int)vy);
             } else {
-                xv = samples[i0 + lane];
+                xv = (G > 1 && pre_i == i0) ? pre_xv : samples[i0 + lane];
             }
         }
         uint32_t xs16[BSM];
@@ -624,27 +654,16 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         const int nsteps = (j0 + CHUNK - 1) / CHUNK;
         {
             uint32_t best[BSM];
+            int c_first = 0;
+            if (G > 1 && pre_i == i0) {  // steps [0, pre_j) were scanned while member 0 committed; unfilled slots held node 0
+                c_first = pre_j / CHUNK;
 #pragma unroll
-            for (int k = 0; k < BSM; ++k) best[k] = NONE;
-            const int nl = nsteps < lds_chunks ? nsteps : lds_chunks;
-            if (nl > 0) {
-                u32x4 cur = nodes_lds4[t];
-                for (int c = 0; c < nl; ++c) {
-                    u32x4 nxt = cur;
-                    if (c + 1 < nl) nxt = nodes_lds4[(c + 1) * TPB + t];
-                    block_scan_step(cur, xs16, best, (uint32_t)c << 2);
-                    cur = nxt;
-                }
+                for (int k = 0; k < BSM; ++k) best[k] = pre_best[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < BSM; ++k) best[k] = NONE;
             }
-            if (nsteps > nl) {
-                u32x4 cur = nodes_g4[nl * TPB + t];
-                for (int c = nl; c < nsteps; ++c) {
-                    u32x4 nxt = cur;
-                    if (c + 1 < nsteps) nxt = nodes_g4[(c + 1) * TPB + t];
-                    block_scan_step(cur, xs16, best, (uint32_t)c << 2);
-                    cur = nxt;
-                }
-            }
+            scan_steps(c_first, nsteps, xs16, best);
             // per sample: wave minimum of d2, lowest index among the lanes that hold it (a lane's best key already
             // carries its lowest such index); gathered into lanes 0..15
             uint32_t gd = NONE, gi = NONE;
@@ -916,6 +935,25 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 for (int w = lane; w < BSM * 10; w += 64) __hip_atomic_store(t_rec + (size_t)g * BSM * 10 + w, src[w], RRT_RLX_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
                 if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
+            }
+            pre_i = -1;
+            if (!informed && i0 + nb < n) {  // the next block's samples are known (only an Informed block can be cut short)
+                pre_i = i0 + nb;
+                pre_j = j0;
+                const int nbn = (n - pre_i) < SB ? (n - pre_i) : SB;
+                pre_xv = lane < nbn ? samples[pre_i + lane] : 0u;
+                uint32_t xsn[BSM];
+#pragma unroll
+                for (int k = 0; k < BSM; ++k) {
+                    const int sk = g * BSM + k;
+                    uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)pre_xv, sk);
+                    if (sk >= nbn) X = (uint32_t)__builtin_amdgcn_readlane((int)pre_xv, 0);
+                    xsn[k] = X << 4;
+                    pre_best[k] = NONE;
+                }
+                scan_steps(0, pre_j / CHUNK, xsn, pre_best);  // whole steps below the first one the commit can touch
+            }
+            if (wave == 0) {
                 const bool ok = team_wait(t_go, epoch, t_fail);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
