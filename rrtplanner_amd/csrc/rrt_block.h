@@ -1031,68 +1031,27 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     if (harmful(kk)) harm |= 1ull << kk;
                 }
             }
+            // ---- C1: decide.  Runs of samples that keep their snapshot result are only marked; a sample that can be affected is
+            //      re-resolved on its own and its record in LDS replaced by the final one.  Nothing is stored to HBM yet: the
+            //      decisions only read the snapshot and the block's samples. ----
+            const double c_ell0 = c_ell;
             while (cur < nb && !cut) {
-                // ---- the run of samples [cur, k0) that commit together ----
                 const u64 pend = __ballot(acc0 && lane >= cur);
                 const u64 Aopt = acc_exact | (pend & ltmask);  // exact below cur, optimistic in [cur, lane)
                 // A sample keeps its snapshot result unless an earlier inserted sample of the block is nearer than its nearest,
                 // sits on its cell, or (accepted samples only) is a harmful candidate parent.
                 const bool slow = lane >= cur && lane < nb && (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || (goalhit && acc0));
                 const unsigned long long bad = __ballot(slow);
-                int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
-                {
-                    const u64 range = lowmask64(k0) & ~lowmask64(cur);
-                    if (j + __builtin_popcountll(pend & range) > n) k0 = cur;  // would overfill: take the exact serial path
-                }
-                if (k0 > cur) {
-                    const u64 range = lowmask64(k0) & ~lowmask64(cur);
-                    const u64 racc = pend & range;
-                    const bool inr = lane >= cur && lane < k0;
-                    const bool myacc = inr && acc0;
-                    const int jmine = j + __builtin_popcountll(racc & ltmask);  // j as this sample sees it
-                    if (inr) {
-                        statred[lane * 5 + 0] += (unsigned long long)jmine;
-                        statred[lane * 5 + 1] += (unsigned long long)(r.los_s & 0x7fffffffu);
-                        if (logs) {
-                            const size_t o = (size_t)q * bv.n_cap + i0 + lane;
-                            bv.nearest_log[o] = (int32_t)r.vs;
-                            bv.accept_log[o] = (uint8_t)myacc;
-                            bv.cbest_log[o] = ell ? c_ell : __longlong_as_double(0x7ff8000000000000ll);
-                            bv.j_log[o] = jmine;
-                        }
-                    }
-                    if (myacc) {
-                        if (star) {
-                            statred[lane * 5 + 2] += r.nnear + (uint32_t)__builtin_popcountll(r.rmask & (acc_exact | (racc & ltmask)));
-                            statred[lane * 5 + 4] += r.pstat >> 20;
-                            statred[lane * 5 + 3] += r.pstat & 0xfffffu;
-                        }
-                        const uint32_t cellbit = (uint32_t)ux(xv) * (uint32_t)H + (uint32_t)uy(xv);
-                        nodes_g[jmine] = xv;
-                        if (jmine < lds_nodes) nodes_lds[jmine] = xv;
-                        vcost[jmine] = r.cbest;
-                        parent[jmine] = (int32_t)r.vbest;
-                        atomicOr(&bitmap[cellbit >> 5], 1u << (cellbit & 31));  // rrt.py:426
-                        newcost[lane] = r.cbest;
-                        if (star) {
-                            const int c = cell_of(xv);
-                            const uint32_t slot = __hip_atomic_fetch_add(&cellcnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const unsigned long long cb = (unsigned long long)__double_as_longlong(r.cbest);
-                            u32x4 rc = {xv, (uint32_t)jmine, (uint32_t)cb, (uint32_t)(cb >> 32)};
-                            cellrec[(size_t)c * (size_t)ccap + slot] = rc;
-                        }
-                    }
-                    acc_exact |= racc;
-                    j += __builtin_popcountll(racc);
-                    cur = k0;
-                }
+                const int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
+                acc_exact |= pend & lowmask64(k0) & ~lowmask64(cur);
+                cur = k0;
                 if (cur >= nb) break;
                 // ---- sample `cur` on its own: re-resolve against snapshot + inserted block nodes ----
                 {
                     const int k = cur;
+                    const int jk = j0 + __builtin_popcountll(acc_exact);  // nodes when this sample is tried
                     const BRec rk = brec[k];
                     const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
-                    const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
                     uint32_t vn = rk.vs, d2n = rk.d2s;
                     double Vn = rk.Vs;
                     bool nocoll = (rk.los_s >> 31) != 0;
@@ -1117,7 +1076,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         nocoll = los_wave(og, H, (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk), Xk, lane, cc);  // rrt.py:424
                         cells = (uint32_t)cc;
                     }
-                    const bool acc = nocoll && !dup && j != n;  // rrt.py:425
+                    const bool acc = nocoll && !dup && jk != n;  // rrt.py:425
                     uint32_t vbest = vn;
                     double cbest = Vn + sqrt_u32(d2n);
                     if (acc && star) {
@@ -1171,56 +1130,76 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             cbest = pc;
                         }
                     }
-                    if (lane == 0) {
-                        statred[0] += (unsigned long long)j;
-                        statred[1] += (unsigned long long)cells;
-                        if (logs) {
-                            const size_t o = (size_t)q * bv.n_cap + i0 + k;
-                            bv.nearest_log[o] = (int32_t)vn;
-                            bv.accept_log[o] = (uint8_t)acc;
-                            bv.cbest_log[o] = ell ? c_ell : __longlong_as_double(0x7ff8000000000000ll);
-                            bv.j_log[o] = j;
-                        }
+                    if (lane == 0) {  // the final record of this sample (pad = 1: nnear already counts the block's nodes)
+                        BRec f = rk;
+                        f.vs = vn;
+                        f.los_s = cells;
+                        f.cbest = cbest;
+                        f.vbest = vbest;
+                        f.pstat = (ntests << 20) | (tcells & 0xfffffu);
+                        f.nnear = nnear;
+                        f.pad = 1;
+                        brec[k] = f;
+                        newcost[k] = cbest;
                     }
                     if (acc) {
-                        if (lane == 0) {
-                            if (star) {
-                                statred[2] += nnear;
-                                statred[4] += ntests;
-                                statred[3] += tcells;
-                            }
-                            nodes_g[j] = Xk;
-                            if (j < lds_nodes) nodes_lds[j] = Xk;
-                            vcost[j] = cbest;
-                            parent[j] = (int32_t)vbest;
-                            atomicOr(&bitmap[cell >> 5], 1u << (cell & 31));  // rrt.py:426
-                            newcost[k] = cbest;
-                            if (star) {
-                                const int c = cell_of(Xk);
-                                const uint32_t slot = __hip_atomic_fetch_add(&cellcnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                const unsigned long long cb = (unsigned long long)__double_as_longlong(cbest);
-                                u32x4 rc = {Xk, (uint32_t)j, (uint32_t)cb, (uint32_t)(cb >> 32)};
-                                cellrec[(size_t)c * (size_t)ccap + slot] = rc;
-                            }
-                        }
                         if (informed && dist2(Xk, xg) < goal_d2) {  // rrt.py:744-745
                             const bool first = nsoln == 0;
                             nsoln++;
                             if (cbest < cmin_soln) {  // np.argmin keeps the first minimum (rrt.py:632)
                                 cmin_soln = cbest;
-                                vbest_soln = j;
+                                vbest_soln = jk;
                                 c_ell = cmin_soln + sqrt_u32(dist2(xg, Xk));
                                 cut = true;  // the ellipse changed: later samples of this block are stale (rrt.py:698-700)
                             }
                             if (first) cut = true;  // sampling switches from free space to the ellipse (rrt.py:695)
                         }
                         acc_exact |= 1ull << k;
-                        j++;
                         const bool redo = lane > k && lane < nb && acc0 && ((r.rmask >> k) & 1ull) != 0;  // its cost is exact now
                         if (__ballot(redo) != 0 && redo) harm = (harm & ~(1ull << k)) | (harmful(k) ? (1ull << k) : 0ull);
                     }
                     cur = k + 1;
                 }
+            }
+            // ---- C2: commit samples [0, cur) in one lane-parallel pass ----
+            {
+                if (j0 + __builtin_popcountll(acc_exact) > n) acc_exact &= ~(1ull << (63 - __builtin_clzll(acc_exact)));  // rrt.py:425 `j != n`: only the run's last sample
+                const bool inr = lane < cur;
+                const BRec f = inr ? brec[lane] : r;
+                const bool myacc = inr && ((acc_exact >> lane) & 1ull) != 0;
+                const int jmine = j0 + __builtin_popcountll(acc_exact & ltmask);  // j as this sample sees it
+                if (inr) {
+                    statred[lane * 5 + 0] += (unsigned long long)jmine;
+                    statred[lane * 5 + 1] += (unsigned long long)(f.los_s & 0x7fffffffu);
+                    if (logs) {
+                        const size_t o = (size_t)q * bv.n_cap + i0 + lane;
+                        bv.nearest_log[o] = (int32_t)f.vs;
+                        bv.accept_log[o] = (uint8_t)myacc;
+                        bv.cbest_log[o] = ell ? c_ell0 : __longlong_as_double(0x7ff8000000000000ll);
+                        bv.j_log[o] = jmine;
+                    }
+                }
+                if (myacc) {
+                    if (star) {
+                        statred[lane * 5 + 2] += f.pad ? f.nnear : f.nnear + (uint32_t)__builtin_popcountll(f.rmask & acc_exact & ltmask);
+                        statred[lane * 5 + 4] += f.pstat >> 20;
+                        statred[lane * 5 + 3] += f.pstat & 0xfffffu;
+                    }
+                    const uint32_t cellbit = (uint32_t)ux(xv) * (uint32_t)H + (uint32_t)uy(xv);
+                    nodes_g[jmine] = xv;
+                    if (jmine < lds_nodes) nodes_lds[jmine] = xv;
+                    vcost[jmine] = f.cbest;
+                    parent[jmine] = (int32_t)f.vbest;
+                    atomicOr(&bitmap[cellbit >> 5], 1u << (cellbit & 31));  // rrt.py:426
+                    if (star) {
+                        const int c = cell_of(xv);
+                        const uint32_t slot = __hip_atomic_fetch_add(&cellcnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const unsigned long long cb = (unsigned long long)__double_as_longlong(f.cbest);
+                        u32x4 rc = {xv, (uint32_t)jmine, (uint32_t)cb, (uint32_t)(cb >> 32)};
+                        cellrec[(size_t)c * (size_t)ccap + slot] = rc;
+                    }
+                }
+                j = j0 + __builtin_popcountll(acc_exact);
             }
             i = i0 + cur;
             if (lane == 0) {
