@@ -712,8 +712,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             const double Vs = vcost[vs];
             const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
             const uint32_t bm_word = bitmap[cell >> 5];
-            int cells = 0;
-            const bool free_s = los_wave(og, H, node_xy(vs), Xk, lane, cells);
+            const uint32_t vsxy = node_xy(vs);
+            const LosPending lp = los_issue(og, H, vsxy, Xk, lane);  // finished behind the near-set stream
             // earlier samples of this block that could interact once inserted
             const uint32_t xo = (lane < sidx) ? xq_lds[lane] : Xk;
             const uint32_t dk = dist2(xo, Xk);
@@ -730,6 +730,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #ifdef RRT_STAMPS
             wcyc_los += __builtin_amdgcn_s_memtime() - tl0;
 #endif
+            int cells = 0;
+            const bool free_s = los_finish(lp, og, H, vsxy, Xk, lane, cells);
             if (lane == 0) {
                 BRec r;
                 r.d2s = d2s;
@@ -773,6 +775,15 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             u64 nnmask = 0, rmask = 0, dupmask = 0;
             const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
             uint32_t own_nlist = 0;
+            uint32_t vsxy = Xk;
+            LosPending lp;
+            lp.major = 0;
+            lp.v = 0;
+            if (lead && act) {  // started here, finished behind the near-set stream
+                bm_word = bitmap[cell >> 5];
+                vsxy = node_xy(vs);
+                lp = los_issue(og, H, vsxy, Xk, lane);
+            }
             if (star) {
                 Top2 tt;
                 tt.init();
@@ -794,8 +805,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             double lbc = -1.0;
             uint32_t lbi = 0;
             if (lead && act) {
-                bm_word = bitmap[cell >> 5];
-                free_s = los_wave(og, H, node_xy(vs), Xk, lane, cells);
+                free_s = los_finish(lp, og, H, vsxy, Xk, lane, cells);
                 // earlier samples of this block that could interact once inserted
                 const uint32_t xo = (lane < sidx) ? xq_lds[lane] : Xk;
                 const uint32_t dk = dist2(xo, Xk);

@@ -138,6 +138,33 @@ __device__ __forceinline__ bool los_wave(const uint8_t *__restrict__ og, int H, 
     return true;
 }
 
+// The same test in two halves for segments shorter than 64 cells: los_issue starts the cell loads, los_finish turns them into
+// the answer.  A lone wave puts independent work (its share of the near-set stream) between the two so that the memory round
+// trip of the test is not on its critical path.  Longer segments are tested in los_finish.
+struct LosPending {
+    int major;
+    uint8_t v;
+};
+__device__ __forceinline__ LosPending los_issue(const uint8_t *__restrict__ og, int H, uint32_t a, uint32_t b, int lane) {
+    const rrt_line_t l = rrt_line_setup(ux(a), uy(a), ux(b), uy(b));
+    LosPending p;
+    p.major = l.major;
+    p.v = 0;
+    if (l.major < 64 && lane <= l.major) {
+        int x, y;
+        rrt_line_cell(&l, lane, &x, &y);
+        p.v = og[(size_t)x * H + y];
+    }
+    return p;
+}
+__device__ __forceinline__ bool los_finish(const LosPending &p, const uint8_t *__restrict__ og, int H, uint32_t a, uint32_t b, int lane,
+                                           int &cells) {
+    if (p.major >= 64) return los_wave(og, H, a, b, lane, cells);
+    const unsigned long long m = __ballot(p.v != 0);
+    cells = m ? (int)__builtin_ctzll(m) + 1 : p.major + 1;
+    return m == 0;
+}
+
 // Two lines of sight a0 -> b and a1 -> b at once (the second only if `has1`): for segments shorter than 64 cells both
 // cell loads are in flight together, so a failed first test does not cost a second memory round trip.
 __device__ __forceinline__ void los_wave2(const uint8_t *__restrict__ og, int H, uint32_t a0, uint32_t a1, bool has1, uint32_t b, int lane,
