@@ -343,6 +343,43 @@ def test_team_that_loses_a_member_finishes_on_one_cu_per_query(gpu_ctx):
     b.close()
 
 
+def test_every_team_size_gives_the_same_trees_every_time(gpu_ctx):
+    """The same 3-query batch on 1, 2, 4, 8, 16, 32 and as many CUs per query as fit, three launches each: every array of every
+    result must be identical (placement, timing and team size must not show; tools/stress_team.py is the long version)."""
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    sg = np.random.default_rng(7)
+    Q, n = 3, 9000
+    qs = []
+    for q in range(Q):
+        xs, xg = random_connected_pair(og, sg)
+        samples = hostprep.draw_free_samples(np.random.default_rng(q), free, n)
+        qs.append(_ffi.make_query(1, n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(64)))
+    ref = None
+    for team in (None, 32, 16, 8, 4, 2, 1):
+        b = _ffi.Batch(gpu_ctx, Q, n, team=team)
+        for q, (qu, keep) in enumerate(qs):
+            b.set_query(q, qu)
+        for rep in range(3):
+            b.rearm()
+            b.launch()
+            b.sync()
+            out = []
+            for q in range(Q):
+                r = b.get_result(q)
+                live = r.j + (1 if r.found else 0)
+                out.append((r.status, r.j, r.vgoal, r.pts[:live].copy(), r.parent[:live].copy(), r.vcost[:live].copy()))
+            if ref is None:
+                ref = out
+            for q in range(Q):
+                assert out[q][:3] == ref[q][:3], (team, rep, q)
+                assert all(np.array_equal(x, y) for x, y in zip(out[q][3:], ref[q][3:])), (team, rep, q)
+        assert b.team()[1] == 0
+        b.close()
+
+
 # ------------------------------------------------------------------------------- properties at full size
 def test_full_size_properties_rrtstar_1024_n50000():
     """BASELINE config 2 (RRT*, 1024x1024, n=50000): size-independent properties of the result --
