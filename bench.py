@@ -303,9 +303,18 @@ def cpu_baseline(og8, cfg, pair, free, state0, ub):
         nodes += r.j - 1
         reps += 1
     dt = time.perf_counter() - t0
-    return {"value": nodes / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
-            "sample": f"query 0 of the same workload (n={n}), {reps} repetition(s), {dt:.1f} s of one host core",
-            "host_cores": os.cpu_count()}
+    out = {"value": nodes / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
+           "sample": f"query 0 of the same workload (n={n}), {reps} repetition(s), {dt:.1f} s of one host core",
+           "host_cores": os.cpu_count()}
+    if alg == 1:
+        # informational: a numpy harness with the reference's per-iteration operation mix (full-capacity array passes, argsort,
+        # Python near-set loop; oracle/numpy_like.py), first iterations of the same query, bounded to ~8 s
+        from oracle import numpy_like
+
+        _, _, _, jl, it, dl = numpy_like.rrtstar_like(og8, n, xs, xg, samples, cfg["r_rewire"], time_limit=8.0)
+        out["reference_like"] = {"value": (jl - 1) / dl, "unit": "nodes/s", "cores": 1,
+                                 "sample": f"first {it} iterations of the same query at capacity n={n}, {dl:.1f} s of one host core, numpy"}
+    return out
 
 
 if __name__ == "__main__":

@@ -193,3 +193,22 @@ def test_policy_B_prefix():
             assert d2[raw[i]] == d2[r.nearest_log[i]] == d2.min(), meta["id"]
         checked += 1
     assert checked >= 6
+
+
+def test_numpy_reference_like_harness_builds_the_oracles_tree():
+    """oracle/numpy_like.py (the "reference-like" CPU timing harness of bench.py) follows the same rules as the oracle."""
+    from oracle import numpy_like
+    from rrtplanner_amd import hostprep
+    from rrtplanner_amd.oggen import perlin_occupancygrid, random_connected_pair
+
+    og = perlin_occupancygrid(160, 120, seed=3)
+    og8 = oracle.og_u8(og)
+    xs, xg = random_connected_pair(og, np.random.default_rng(5))
+    free = np.argwhere(og8 == 0)
+    n = 900
+    samples = hostprep.draw_free_samples(np.random.default_rng(1), free, n)
+    pts, par, vc, j, it, _ = numpy_like.rrtstar_like(og8, n, xs, xg, samples, 18)
+    st, ro = oracle.plan(og8, n, 1, xs, xg, samples, r2_rewire=hostprep.radius_threshold(18))
+    assert it == n and j == ro.j
+    assert np.array_equal(pts[:j], ro.pts[:j]) and np.array_equal(vc[:j], ro.vcost[:j])
+    assert all(par[c] == ro.parent[c] for c in range(1, j))
