@@ -17,11 +17,17 @@ xs, xg = random_connected_pair(og, np.random.default_rng(7))
 mk = {"standard": lambda: RRTStandard(og, a.n, pbar=False, seed=0), "star": lambda: RRTStar(og, a.n, 64, pbar=False, seed=0),
       "informed": lambda: RRTStarInformed(og, a.n, 64, 12, pbar=False, seed=0)}[a.alg]
 p = mk()
+T = None
 for r in range(a.reps):
+    del T  # freeing a materialised 50 000-node graph takes longer than planning the next one: keep it out of the timing
     t0 = time.perf_counter()
     T, gv = p.plan(xs, xg)
     t1 = time.perf_counter()
     path = p.route2gv(T, gv)
     t2 = time.perf_counter()
-    st = getattr(p, "last_stats", None)
-    print(f"rep {r}: plan() {1e3 * (t1 - t0):.1f} ms, route2gv {1e3 * (t2 - t1):.2f} ms, nodes {T.number_of_nodes()}, path {len(path)} vertices, stats {st}")
+    segs = p.vertices_as_ndarray(T, path)
+    t3 = time.perf_counter()
+    nn = T.number_of_nodes()  # first touch of the graph itself: fills the dictionaries
+    t4 = time.perf_counter()
+    print(f"rep {r}: plan() {1e3 * (t1 - t0):.1f} ms, route2gv {1e3 * (t2 - t1):.2f} ms, vertices_as_ndarray {1e3 * (t3 - t2):.2f} ms, "
+          f"materialising the DiGraph ({nn} nodes) {1e3 * (t4 - t3):.1f} ms, path {len(path)} vertices, j {p.last_stats['j']}")
