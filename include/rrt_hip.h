@@ -40,6 +40,8 @@ extern "C" {
                               largest for which all teams of the batch are resident on the device together */
 #define RRT_FLAG_TEAM_FAULT 8u /* testing: one member of every team leaves at once; the hand-offs of the others time out
                                   and the batch must finish with one CU per query */
+#define RRT_FLAG_NOPIPE 16u /* teams of 8 and more CUs: do not pipeline super-blocks (the commit of block s under the resolution
+                              of block s + 1; RRTStandard / RRTStar only) */
 #define RRT_FLAG_TEAM_MAX(g) ((uint32_t)(g) << 8) /* cap the team size at g CUs per query (g = 2, 4, ... 64; 0 = no cap) */
 
 typedef struct rrt_ctx rrt_ctx;

@@ -47,8 +47,8 @@ constexpr int CG = 2;   // cells whose records an owner streams concurrently
 // All members must be resident together (the launch keeps teams x G <= CUs); every spin is bounded by a wall-clock
 // limit that fails the query (status ST_TEAM_FAIL) instead of hanging the device.
 constexpr int TEAM_MAX = 64;
-constexpr int TEAM_BYTES = 16384;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
-constexpr int TEAM_OFF_ARRIVE = 6144, TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384, TEAM_OFF_REC = 512;
+constexpr int TEAM_BYTES = 24576;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
+constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 2 x 64 */, TEAM_OFF_REC = 512 /* 2 x 6656 */, TEAM_OFF_ARRIVE = 13824 /* 65 x 128 */;
 constexpr unsigned long long TEAM_TIMEOUT_TICKS = 50000000ull;  // 0.5 s of the 100 MHz wall clock
 
 typedef unsigned long long u64;
@@ -58,11 +58,12 @@ typedef __attribute__((address_space(1))) u64 gu64;
 
 __device__ __forceinline__ u64 lowmask64(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
 
-// One wave polls the arrival flags of members 1..G-1 (lane g: member g's flag, 128 bytes apart) until all have reached `target`.
-__device__ __forceinline__ bool team_wait_all(gu32 *flags, int G, uint32_t target, gu32 *fail, int lane) {
+// One wave polls the arrival flags of `count` members starting with member `first` (lane l: member first + l, flags 128 bytes
+// apart) until all have reached `target`.
+__device__ __forceinline__ bool team_wait_all(gu32 *flags, int first, int count, uint32_t target, gu32 *fail, int lane) {
     const u64 t0 = wall_clock64();
     for (;;) {
-        const bool mine = (lane >= 1 && lane < G) ? __hip_atomic_load(flags + 32 * lane, RRT_RLX_AGENT) >= target : true;
+        const bool mine = lane < count ? __hip_atomic_load(flags + 32 * (first + lane), RRT_RLX_AGENT) >= target : true;
         if (__all(mine)) return true;
         if (__hip_atomic_load(fail, RRT_RLX_AGENT) != 0u) return false;
         if (wall_clock64() - t0 > TEAM_TIMEOUT_TICKS) {
@@ -112,7 +113,7 @@ __device__ __forceinline__ uint32_t key16(uint32_t node_s, uint32_t q_s, uint32_
     return r;
 }
 
-// Owner's publication for one sample (80 bytes = 10 words of 8 bytes).
+// Owner's publication for one sample (104 bytes = 13 words of 8 bytes).
 struct BRec {
     uint32_t d2s, vs;   // snapshot nearest
     uint32_t los_s;     // line of sight vs -> sample: bit 31 free, low bits cells read
@@ -127,11 +128,13 @@ struct BRec {
     u64 nnmask;         // earlier samples of the (super-)block strictly nearer than the snapshot nearest
     u64 rmask;          // earlier samples within r_rewire
     u64 dupmask;        // earlier samples on the same cell
+    u64 pnn, pr, pdup;  // pipelined teams: the same three masks against the samples of the previous super-block
 };
-static_assert(sizeof(BRec) == 80, "BRec must be 80 bytes");
+constexpr int BREC_WORDS = 13;
+static_assert(sizeof(BRec) == 8 * BREC_WORDS, "BRec must be 104 bytes");
 union BRecWords {
     BRec r;
-    u64 w[10];
+    u64 w[BREC_WORDS];
 };
 
 // Block state that wave 0 hands to the other waves after the commit.
@@ -168,9 +171,14 @@ union BlkWords {
     u64 w[5];
 };
 
-template <int G, int BSM>
+// PIPE (teams of RRTStandard / RRTStar queries): G workers plus one workgroup that only commits, and a two-deep pipeline --
+// while block s is committed the workers already resolve block s + 1 against the tree as it stood BEFORE block s; every
+// record then also carries the three interaction masks against the samples of block s, and the commit of block s + 1 treats
+// the nodes block s inserted like inserted samples of its own block (their acceptance and costs are exact by then).
+template <int G, int BSM, bool PIPE>
 __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM <= BS && BSM * G <= 64, "team size");
+    static_assert(!PIPE || G > 1, "a pipeline needs a team");
     constexpr int SB = BSM * G;  // samples per (super-)block: one lane of the committing wave each; BSM per member
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
     __shared__ __attribute__((aligned(16))) u32x2 nnx[BSM * NWAVE];        // per own sample, per wave: {d2, idx}
@@ -180,6 +188,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     __shared__ __attribute__((aligned(16))) unsigned long long statred[SB * 5];
     __shared__ uint32_t xq_lds[SB];
     __shared__ double newcost[SB];
+    __shared__ uint32_t xqp_lds[PIPE ? 64 : 1];   // pipelined teams: the samples of the previous super-block ...
+    __shared__ double prevcost[PIPE ? 64 : 1];    // ... and (committer) the exact costs of the nodes it inserted
     constexpr int WPS = NWAVE / BSM;  // waves per sample in the owner phase
     __shared__ __attribute__((aligned(16))) GSlot gslot[NWAVE];
     __shared__ __attribute__((aligned(16))) GCtl gctl[BSM];
@@ -191,11 +201,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         if (q >= bv.Q) return;
         if (bv.team_fault && g == 1) return;
     }
+    const bool worker = !PIPE || g > 0;  // scans and resolves samples (a pipelined team's member 0 only commits)
+    const int wg = PIPE ? g - 1 : g;     // which BSM samples of a super-block this workgroup owns
     QDesc *D = bv.desc + q;
     if (D->status != ST_RUNNING) return;
     unsigned char *tb = (G > 1) ? bv.team + (size_t)q * TEAM_BYTES : nullptr;
     gu32 *const t_arrive = (gu32 *)(tb + TEAM_OFF_ARRIVE), *const t_go = (gu32 *)(tb + TEAM_OFF_GO), *const t_fail = (gu32 *)(tb + TEAM_OFF_FAIL);
-    gu64 *const t_state = (gu64 *)(tb + TEAM_OFF_STATE), *const t_rec = (gu64 *)(tb + TEAM_OFF_REC);
+    gu64 *const t_state = (gu64 *)(tb + TEAM_OFF_STATE), *const t_rec = (gu64 *)(tb + TEAM_OFF_REC);  // PIPE: two of each, by block parity
     uint32_t epoch = 0;  // super-blocks of this launch so far
     // pre-scan (team members, RRTStandard / RRTStar): while member 0 commits block s, a member already scans the snapshot of
     // block s for the samples of block s + 1; after the commit only the steps that hold the new nodes are scanned again
@@ -204,6 +216,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #pragma unroll
     for (int k = 0; k < BSM; ++k) pre_best[k] = NONE;
     bool team_failed = false;
+    u64 A_prev = 0;  // pipelined committer: the samples of the previous block that were inserted, and the node count before them
+    int jp0 = 0;
 
     // ---- per-query views ----
     const int n = D->n, alg = D->alg;
@@ -282,7 +296,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     //                  the second cheapest so far.
     //   consume_list   only when both are blocked: the parked list is priced and the entries still open are tested.
     //   count_tests    the statistics as the sequential loop counts them.
-    const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE * G));  // the engine sizes the spill area per team member
+    const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE * (G + (PIPE ? 1 : 0))));  // the engine sizes the spill area per team member
     u32x4 *const clist_base = reinterpret_cast<u32x4 *>(spill) + (size_t)(g * NWAVE) * (size_t)clist_cap;  // this member's 16 lists
     u32x4 *const clist = clist_base + (size_t)wave * (size_t)clist_cap;
     // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
@@ -585,7 +599,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     };
 
     // steps [c0, c1) of the scan: 4096 nodes per step, from the LDS cache or (beyond it) from HBM, next step prefetched
-    auto scan_steps = [&](int c0, int c1, const uint32_t (&xs16)[BSM], uint32_t (&best)[BSM]) {
+    const uint32_t node0 = xs;  // node 0 = the start
+    auto scan_steps = [&](int c0, int c1, int jlim, const uint32_t (&xs16)[BSM], uint32_t (&best)[BSM]) {
         const int nl = c1 < lds_chunks ? c1 : lds_chunks;
         if (c0 < nl) {
             u32x4 cur = nodes_lds4[c0 * TPB + t];
@@ -602,6 +617,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             for (int c = g0; c < c1; ++c) {
                 u32x4 nxt = cur;
                 if (c + 1 < c1) nxt = nodes_g4[(c + 1) * TPB + t];
+                if (PIPE) {  // the committer may be appending nodes beyond this worker's snapshot right now: read them as node 0
+                    const int base = c * CHUNK + 4 * t;
+                    if (base + 0 >= jlim) cur.x = node0;
+                    if (base + 1 >= jlim) cur.y = node0;
+                    if (base + 2 >= jlim) cur.z = node0;
+                    if (base + 3 >= jlim) cur.w = node0;
+                }
                 block_scan_step<BSM>(cur, xs16, best, (uint32_t)c << 2);
                 cur = nxt;
             }
@@ -638,13 +660,15 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 vy = (vy > 0.0) ? vy : 0.0;
                 xv = pack_xy((int)vx, (int)vy);
             } else {
-                xv = (G > 1 && pre_i == i0) ? pre_xv : samples[i0 + lane];
+                xv = (G > 1 && !PIPE && pre_i == i0) ? pre_xv : samples[i0 + lane];
             }
         }
+        if (!worker && t < SB) xq_lds[t] = xv;  // a pipelined team's committer: nothing to resolve
+        if (worker) {
         uint32_t xs16[BSM];
 #pragma unroll
-        for (int k = 0; k < BSM; ++k) {  // this member's samples [BSM g, BSM (g + 1))
-            const int sk = g * BSM + k;
+        for (int k = 0; k < BSM; ++k) {  // this member's samples [BSM wg, BSM (wg + 1))
+            const int sk = wg * BSM + k;
             uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)xv, sk);
             if (sk >= nb) X = (uint32_t)__builtin_amdgcn_readlane((int)xv, 0);
             xs16[k] = X << 4;
@@ -655,7 +679,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         {
             uint32_t best[BSM];
             int c_first = 0;
-            if (G > 1 && pre_i == i0) {  // steps [0, pre_j) were scanned while member 0 committed; unfilled slots held node 0
+            if (G > 1 && !PIPE && pre_i == i0) {  // steps [0, pre_j) were scanned while member 0 committed; unfilled slots held node 0
                 c_first = pre_j / CHUNK;
 #pragma unroll
                 for (int k = 0; k < BSM; ++k) best[k] = pre_best[k];
@@ -663,7 +687,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #pragma unroll
                 for (int k = 0; k < BSM; ++k) best[k] = NONE;
             }
-            scan_steps(c_first, nsteps, xs16, best);
+            scan_steps(c_first, nsteps, j0, xs16, best);
             // per sample: wave minimum of d2, lowest index among the lanes that hold it (a lane's best key already
             // carries its lowest such index); gathered into lanes 0..15
             uint32_t gd = NONE, gi = NONE;
@@ -698,7 +722,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
         if constexpr (WPS == 1) {
-        const int sidx = g * BSM + wave;  // the sample this wave owns (waves BSM.. of a small-BSM team member idle here)
+        const int sidx = wg * BSM + wave;  // the sample this wave owns (waves BSM.. of a small-BSM team member idle here)
         if (wave < BSM && sidx < nb) {
             const int k = wave;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, sidx);  // every wave holds the same xv
@@ -748,6 +772,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.nnear = nnear;
                 r.pad = 0;
                 r.pc = pc;
+                r.pnn = r.pr = r.pdup = 0;
                 brec[sidx] = r;
             }
         }
@@ -755,7 +780,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             // ---- a group of WPS waves per sample: every wave streams its share of the cells; the group's first wave (leader)
             //      combines, tests lines of sight and writes the record; blocked-candidate lists are tested by all WPS waves ----
             const int sl = wave / WPS, part = wave % WPS;
-            const int sidx = g * BSM + sl;
+            const int sidx = wg * BSM + sl;
             const bool act = sidx < nb, lead = part == 0;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, act ? sidx : 0);
             uint32_t d2s = NONE, vs = NONE;
@@ -772,7 +797,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             bool free_s = false;
             int cells = 0;
             uint32_t bm_word = 0;
-            u64 nnmask = 0, rmask = 0, dupmask = 0;
+            u64 nnmask = 0, rmask = 0, dupmask = 0, pnn = 0, pr = 0, pdup = 0;
             const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
             uint32_t own_nlist = 0;
             uint32_t vsxy = Xk;
@@ -812,6 +837,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 nnmask = __ballot(lane < sidx && dk < d2s);
                 rmask = __ballot(lane < sidx && star && dk < r2);
                 dupmask = __ballot(lane < sidx && xo == Xk);
+                if (PIPE && epoch >= 2) {  // ... and every sample of the previous block, which is being committed meanwhile
+                    const uint32_t xop = xqp_lds[lane];
+                    const uint32_t dp = dist2(xop, Xk);
+                    pnn = __ballot(dp < d2s);
+                    pr = __ballot(star && dp < r2);
+                    pdup = __ballot(xop == Xk);
+                }
                 if (star) {
                     Top2 tt;
                     tt.init();
@@ -926,6 +958,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.nnear = nnear;
                 r.pad = 0;
                 r.pc = pc;
+                r.pnn = pnn;
+                r.pr = pr;
+                r.pdup = pdup;
                 brec[sidx] = r;
             }
         }
@@ -935,14 +970,56 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         STAMP(2);
         __syncthreads();
         STAMP(3);
+        }  // worker
+
+        // ---------------- a pipelined team's workers: hand the records of block s over and, instead of waiting for its commit,
+        //                  take the nodes of the commit of block s - 1 and go on with block s + 1 ----------------
+        if (PIPE && g > 0) {
+            const bool more = i0 + nb < n;
+            if (wave == 0) {
+                const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[wg * BSM];
+                gu64 *dst = t_rec + (size_t)(epoch & 1u) * 64 * BREC_WORDS + (size_t)wg * BSM * BREC_WORDS;
+                for (int w = lane; w < BSM * BREC_WORDS; w += 64) __hip_atomic_store(dst + w, src[w], RRT_RLX_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
+                if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
+                bool ok = true;
+                if (epoch >= 2 && more) {
+                    ok = team_wait(t_go, epoch - 1, t_fail);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
+                }
+                if (lane == 0) blk.pad0 = ok ? 0 : 1;
+                xqp_lds[lane] = xv;  // the next block's "previous" samples (a block that has a successor is full)
+            }
+            __syncthreads();
+            if (blk.pad0 != 0) {
+                team_failed = true;
+                break;
+            }
+            if (epoch >= 2 && more) {
+                BlkWords u;
+#pragma unroll
+                for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + (size_t)((epoch - 1) & 1u) * 8 + w, RRT_RLX_AGENT);
+                const int jn = u.b.j;
+                if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
+                    const uint32_t Xn = nodes_g[j0 + t];
+                    if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
+                    if (star) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                j = jn;
+            }
+            i = i0 + nb;
+            __syncthreads();
+            continue;
+        }
 
         // ---------------- team members g > 0: hand the records over, wait for the commit, take the new nodes ----------------
-        if (G > 1 && g > 0) {
+        if (G > 1 && !PIPE && g > 0) {
             if (wave == 0) {
                 // this member's 16 records, LDS -> HBM: whole 128-byte lines per wave instruction, write-through (8-byte
                 // stores of single lanes are partial-line fabric writes and delay everything queued behind them)
                 const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[g * BSM];
-                for (int w = lane; w < BSM * 10; w += 64) __hip_atomic_store(t_rec + (size_t)g * BSM * 10 + w, src[w], RRT_RLX_AGENT);
+                for (int w = lane; w < BSM * BREC_WORDS; w += 64) __hip_atomic_store(t_rec + (size_t)g * BSM * BREC_WORDS + w, src[w], RRT_RLX_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
                 if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
             }
@@ -961,7 +1038,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     xsn[k] = X << 4;
                     pre_best[k] = NONE;
                 }
-                scan_steps(0, pre_j / CHUNK, xsn, pre_best);  // whole steps below the first one the commit can touch
+                scan_steps(0, pre_j / CHUNK, pre_j, xsn, pre_best);  // whole steps below the first one the commit can touch
             }
             if (wave == 0) {
                 const bool ok = team_wait(t_go, epoch, t_fail);
@@ -996,12 +1073,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         // ---------------- C: commit (wave 0 of member 0) ----------------
         if (wave == 0) {
             bool remote_ok = true;
-            if (G > 1) {  // the other members' records: poll the arrival counter, then loads that bypass the L1
-                remote_ok = team_wait_all(t_arrive, G, epoch, t_fail, lane);
-                if (remote_ok && lane >= BSM && lane < nb) {
+            if (G > 1) {  // the other members' records: poll the arrival flags, then loads that bypass the L1
+                remote_ok = team_wait_all(t_arrive, 1, PIPE ? G : G - 1, epoch, t_fail, lane);
+                if (remote_ok && (PIPE || lane >= BSM) && lane < nb) {
+                    const gu64 *src = t_rec + (PIPE ? (size_t)(epoch & 1u) * 64 * BREC_WORDS : 0) + (size_t)lane * BREC_WORDS;
                     BRecWords u;
 #pragma unroll
-                    for (int w = 0; w < 10; ++w) u.w[w] = __hip_atomic_load(t_rec + (size_t)lane * 10 + w, RRT_RLX_AGENT);
+                    for (int w = 0; w < BREC_WORDS; ++w) u.w[w] = __hip_atomic_load(src + w, RRT_RLX_AGENT);
                     brec[lane] = u.r;
                 }
             }
@@ -1010,7 +1088,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             } else {
             BRec r;
             r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnear = r.pad = 0;
-            r.nnmask = r.rmask = r.dupmask = 0;
+            r.nnmask = r.rmask = r.dupmask = r.pnn = r.pr = r.pdup = 0;
             r.Vs = r.cbest = r.pc = 0.0;
             if (lane < nb) r = brec[lane];  // lane s: sample s
             const bool acc0 = lane < nb && (r.los_s >> 31) != 0 && (r.flags & 1u) == 0;  // accepted if nothing in the block interferes
@@ -1041,6 +1119,23 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     if (harmful(kk)) harm |= 1ull << kk;
                 }
             }
+            // pipelined: the nodes the previous block inserted are exact; the samples of this block were resolved without them
+            if (PIPE && epoch == 1) jp0 = j0;
+            u64 pbad = 0;  // inserted samples of the previous block that affect this sample
+            if (PIPE && lane < nb) {
+                pbad = (r.pnn | r.pdup) & A_prev;
+                if (acc0) {
+                    u64 rm = r.pr & A_prev;
+                    while (rm) {
+                        const int kk = __builtin_ctzll(rm);
+                        rm &= rm - 1;
+                        const uint32_t d2 = dist2(xqp_lds[kk], xv);
+                        const double nc = prevcost[kk];
+                        const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
+                        if (low < screen_of(r.cbest) && nc + sqrt_u32(d2) < r.cbest) pbad |= 1ull << kk;
+                    }
+                }
+            }
             // ---- C1: decide.  Runs of samples that keep their snapshot result are only marked; a sample that can be affected is
             //      re-resolved on its own and its record in LDS replaced by the final one.  Nothing is stored to HBM yet: the
             //      decisions only read the snapshot and the block's samples. ----
@@ -1050,7 +1145,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 const u64 Aopt = acc_exact | (pend & ltmask);  // exact below cur, optimistic in [cur, lane)
                 // A sample keeps its snapshot result unless an earlier inserted sample of the block is nearer than its nearest,
                 // sits on its cell, or (accepted samples only) is a harmful candidate parent.
-                const bool slow = lane >= cur && lane < nb && (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || (goalhit && acc0));
+                const bool slow = lane >= cur && lane < nb && (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || pbad != 0 || (goalhit && acc0));
                 const unsigned long long bad = __ballot(slow);
                 const int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
                 acc_exact |= pend & lowmask64(k0) & ~lowmask64(cur);
@@ -1071,19 +1166,34 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     uint32_t ntests = rk.pstat >> 20, tcells = rk.pstat & 0xfffffu;
                     const uint32_t xo = (lane < SB) ? xq_lds[lane] : Xk;  // lane kk: sample kk
                     const uint32_t dk = dist2(xo, Xk);
-                    const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_exact) != 0;
+                    // pipelined: lane kk also stands for sample kk of the previous block (inserted ones: A_prev, exact costs)
+                    const uint32_t xop = PIPE ? xqp_lds[lane] : Xk;
+                    const uint32_t dkp = dist2(xop, Xk);
+                    const int snapj = PIPE ? jp0 : j0;  // the node count the sample's owner resolved it against
+                    const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_exact) != 0 || (PIPE && (rk.pdup & A_prev) != 0);
                     const u64 nm = rk.nnmask & acc_exact;
+                    const u64 pnm = PIPE ? (rk.pnn & A_prev) : 0ull;
                     bool nn_inblock = false;
-                    if (nm) {  // nearest is an inserted block node: smallest distance, earliest sample on ties
-                        uint32_t kd = (nm & lbit) ? dk : NONE;
-                        uint32_t kk = (uint32_t)lane;
+                    if (nm | pnm) {  // nearest is an inserted block node: smallest distance, lowest node index on ties
+                        uint32_t kd = (nm & lbit) ? dk : NONE, kk = (uint32_t)lane;
                         wave_min_key_idx(kd, kk);
+                        uint32_t kdp = (pnm & lbit) ? dkp : NONE, kkp = (uint32_t)lane;
+                        wave_min_key_idx(kdp, kkp);
                         nn_inblock = true;
-                        d2n = kd;
-                        vn = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & lowmask64((int)kk));
-                        Vn = newcost[kk];
+                        uint32_t axy;
+                        if (pnm != 0 && (nm == 0 || kdp <= kd)) {  // a node of the previous block (its indices are the lower ones)
+                            d2n = kdp;
+                            vn = (uint32_t)jp0 + (uint32_t)__builtin_popcountll(A_prev & lowmask64((int)kkp));
+                            Vn = prevcost[kkp];
+                            axy = (uint32_t)__builtin_amdgcn_readlane((int)xop, (int)kkp);
+                        } else {
+                            d2n = kd;
+                            vn = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & lowmask64((int)kk));
+                            Vn = newcost[kk];
+                            axy = (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk);
+                        }
                         int cc = 0;
-                        nocoll = los_wave(og, H, (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk), Xk, lane, cc);  // rrt.py:424
+                        nocoll = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:424
                         cells = (uint32_t)cc;
                     }
                     const bool acc = nocoll && !dup && jk != n;  // rrt.py:425
@@ -1096,7 +1206,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             if (cnear > cnear_s) {  // entries between the two bounds were never priced: redo the snapshot part
                                 ntests = 0;
                                 tcells = 0;
-                                snapshot_parent(Xk, j0, true, cnear, pc, pi, nnear, ntests, tcells);
+                                snapshot_parent(Xk, snapj, true, cnear, pc, pi, nnear, ntests, tcells);
                             } else if (pi != NONE && !(pc < cnear)) {
                                 pc = f64_inf();
                                 pi = NONE;
@@ -1104,8 +1214,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         }
                         // inserted block nodes within r_rewire, in (cost, index) order, while they beat the snapshot's best
                         u64 rm = rk.rmask & acc_exact;
-                        nnear += (uint32_t)__builtin_popcountll(rm);
-                        while (rm) {
+                        u64 rmp = PIPE ? (rk.pr & A_prev) : 0ull;
+                        nnear += (uint32_t)__builtin_popcountll(rm) + (uint32_t)__builtin_popcountll(rmp);
+                        while (rm | rmp) {
                             double cn = f64_inf();
                             uint32_t ci = NONE;
                             if (rm & lbit) {
@@ -1117,15 +1228,40 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                                 }
                             }
                             wave_min_f64_idx(cn, ci);
+                            bool from_prev = false;
+                            if (PIPE && rmp != 0) {
+                                double cp = f64_inf();
+                                uint32_t cip = NONE;
+                                if (rmp & lbit) {
+                                    cp = prevcost[lane] + sqrt_u32(dkp);
+                                    cip = (uint32_t)jp0 + (uint32_t)__builtin_popcountll(A_prev & ltmask);
+                                    if (!(cp < cnear)) {
+                                        cp = f64_inf();
+                                        cip = NONE;
+                                    }
+                                }
+                                wave_min_f64_idx(cp, cip);
+                                if (cip != NONE && (ci == NONE || key_lt(cp, cip, cn, ci))) {
+                                    cn = cp;
+                                    ci = cip;
+                                    from_prev = true;
+                                }
+                            }
                             if (ci == NONE || !key_lt(cn, ci, pc, pi)) break;
-                            uint32_t kk = 0;  // which sample is node ci
-                            {
+                            uint32_t kk = 0, axy;  // which sample is node ci
+                            if (from_prev) {
+                                u64 am = A_prev;
+                                for (uint32_t c = 0; c < ci - (uint32_t)jp0; ++c) am &= am - 1;
+                                kk = (uint32_t)__builtin_ctzll(am);
+                                axy = (uint32_t)__builtin_amdgcn_readlane((int)xop, (int)kk);
+                            } else {
                                 u64 am = acc_exact;
                                 for (uint32_t c = 0; c < ci - (uint32_t)j0; ++c) am &= am - 1;
                                 kk = (uint32_t)__builtin_ctzll(am);
+                                axy = (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk);
                             }
                             int cc = 0;
-                            const bool ok = los_wave(og, H, (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk), Xk, lane, cc);  // rrt.py:519
+                            const bool ok = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:519
                             ntests += 1;
                             tcells += (uint32_t)cc;
                             if (ok) {
@@ -1133,7 +1269,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                                 pi = ci;
                                 break;
                             }
-                            rm &= ~(1ull << kk);
+                            if (from_prev) rmp &= ~(1ull << kk);
+                            else rm &= ~(1ull << kk);
                         }
                         if (pi != NONE) {
                             vbest = pi;
@@ -1191,7 +1328,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 }
                 if (myacc) {
                     if (star) {
-                        statred[lane * 5 + 2] += f.pad ? f.nnear : f.nnear + (uint32_t)__builtin_popcountll(f.rmask & acc_exact & ltmask);
+                        statred[lane * 5 + 2] += f.pad ? f.nnear
+                                                       : f.nnear + (uint32_t)__builtin_popcountll(f.rmask & acc_exact & ltmask) +
+                                                             (PIPE ? (uint32_t)__builtin_popcountll(f.pr & A_prev) : 0u);
                         statred[lane * 5 + 4] += f.pstat >> 20;
                         statred[lane * 5 + 3] += f.pstat & 0xfffffu;
                     }
@@ -1210,6 +1349,12 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     }
                 }
                 j = j0 + __builtin_popcountll(acc_exact);
+                if (PIPE) {  // this block becomes the previous one
+                    xqp_lds[lane] = xv;
+                    prevcost[lane] = f.cbest;
+                    A_prev = acc_exact;
+                    jp0 = j0;
+                }
             }
             i = i0 + cur;
             if (lane == 0) {
@@ -1226,7 +1371,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     BlkWords u;
                     u.b = b;
 #pragma unroll
-                    for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + w, u.w[w], RRT_RLX_AGENT);
+                    for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + (PIPE ? (size_t)(epoch & 1u) * 8 : 0) + w, u.w[w], RRT_RLX_AGENT);
                 }
             }
             if (G > 1) {

@@ -43,6 +43,7 @@ struct rrt_batch {
     int32_t blk_lds_chunks = 1; // node chunks cached in LDS by the block kernel
     size_t blk_lds_bytes = 0;
     int32_t team = 1;           // workgroups (CUs) per query of the block kernel (rrt_block.h, teams)
+    bool pipe = false;          // the last launch ran the pipelined team kernel
     int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
     int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
     unsigned char *d_team = nullptr;  // [Q][TEAM_BYTES] sync words, state, exchanged records; zeroed before every launch
@@ -63,7 +64,7 @@ struct rrt_batch {
     std::vector<uint32_t> stage;  // host staging for packed samples
 };
 
-static const void *block_kernel_of(int team);
+static const void *block_kernel_of(int team, bool pipe = false);
 static size_t block_kernel_static_lds(int team);
 
 static int fail(rrt_ctx *ctx, int code, const char *fmt, ...) {
@@ -343,7 +344,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
             }
         }
     }
-    b->spill_stride = chunks * CHUNK * b->team;  // per member: 256 parked entries per wave and node chunk; also go2goal's cost array
+    b->spill_stride = chunks * CHUNK * (b->team + 1);  // per member (and a pipelined team's committer): 256 parked entries per wave and node chunk; also go2goal's cost array
     {   // block kernel LDS: [node cache | cell fill counts 16 KiB]
         const size_t budget = (size_t)ctx->max_lds - block_kernel_static_lds(b->team);
         const size_t fixed = (size_t)MAX_CELLS * sizeof(uint32_t);
@@ -516,22 +517,39 @@ static BatchView make_view(rrt_batch *b) {
     return v;
 }
 
-static const void *block_kernel_of(int team) {
+typedef void (*block_kernel_fn)(BatchView);
+
+static block_kernel_fn block_kernel_fn_of(int team, bool pipe) {
+    if (pipe) {
+        switch (team) {
+            case 64: return rrt_expand_block_kernel<64, 1, true>;
+            case 32: return rrt_expand_block_kernel<32, 2, true>;
+            case 16: return rrt_expand_block_kernel<16, 4, true>;
+            default: return rrt_expand_block_kernel<8, 8, true>;
+        }
+    }
     switch (team) {
-        case 64: return reinterpret_cast<const void *>(rrt_expand_block_kernel<64, 1>);
-        case 32: return reinterpret_cast<const void *>(rrt_expand_block_kernel<32, 2>);
-        case 16: return reinterpret_cast<const void *>(rrt_expand_block_kernel<16, 4>);
-        case 8: return reinterpret_cast<const void *>(rrt_expand_block_kernel<8, 8>);
-        case 4: return reinterpret_cast<const void *>(rrt_expand_block_kernel<4, 16>);
-        case 2: return reinterpret_cast<const void *>(rrt_expand_block_kernel<2, 16>);
-        default: return reinterpret_cast<const void *>(rrt_expand_block_kernel<1, 16>);
+        case 64: return rrt_expand_block_kernel<64, 1, false>;
+        case 32: return rrt_expand_block_kernel<32, 2, false>;
+        case 16: return rrt_expand_block_kernel<16, 4, false>;
+        case 8: return rrt_expand_block_kernel<8, 8, false>;
+        case 4: return rrt_expand_block_kernel<4, 16, false>;
+        case 2: return rrt_expand_block_kernel<2, 16, false>;
+        default: return rrt_expand_block_kernel<1, 16, false>;
     }
 }
 
+static const void *block_kernel_of(int team, bool pipe) { return reinterpret_cast<const void *>(block_kernel_fn_of(team, pipe)); }
+
 static size_t block_kernel_static_lds(int team) {
     hipFuncAttributes a{};
-    if (hipFuncGetAttributes(&a, block_kernel_of(team)) != hipSuccess) return 16384;
-    return (a.sharedSizeBytes + 255) & ~(size_t)255;
+    size_t worst = 0;
+    for (bool pipe : {false, true}) {
+        if (pipe && team < 8) continue;
+        if (hipFuncGetAttributes(&a, block_kernel_of(team, pipe)) != hipSuccess) return 16384;
+        worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+    }
+    return (worst + 255) & ~(size_t)255;
 }
 
 static size_t expand_lds_bytes(int lds_chunks) {
@@ -548,25 +566,19 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
     if (b->use_block) {
         v.lds_chunks = b->blk_lds_chunks;
-        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(b->team), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
+        // a two-deep pipeline of super-blocks (one more workgroup per team, which only commits) for teams of 8 and more whose
+        // queries are all RRTStandard / RRTStar (an Informed block can end early or change the samples of the next one)
+        bool pipe = b->team >= 8 && !(b->flags & RRT_FLAG_NOPIPE) && b->team_qpad * (b->team + 1) <= ctx->num_cu;
+        if (const char *e = getenv("RRT_PIPE")) pipe = pipe && atoi(e) != 0;
+        for (const auto &d : b->h_desc)
+            if (d.status == ST_RUNNING && d.alg == 2) pipe = false;
+        b->pipe = pipe;
+        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(b->team, pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         if (b->team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
-        const dim3 tg((unsigned)(b->team_qpad * b->team));
-        if (b->team == 64)
-            hipLaunchKernelGGL((rrt_expand_block_kernel<64, 1>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
-        else if (b->team == 32)
-            hipLaunchKernelGGL((rrt_expand_block_kernel<32, 2>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
-        else if (b->team == 16)
-            hipLaunchKernelGGL((rrt_expand_block_kernel<16, 4>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
-        else if (b->team == 8)
-            hipLaunchKernelGGL((rrt_expand_block_kernel<8, 8>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
-        else if (b->team == 4)
-            hipLaunchKernelGGL((rrt_expand_block_kernel<4, 16>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
-        else if (b->team == 2)
-            hipLaunchKernelGGL((rrt_expand_block_kernel<2, 16>), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
-        else
-            hipLaunchKernelGGL((rrt_expand_block_kernel<1, 16>), dim3((unsigned)b->Q), dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        const dim3 tg(b->team > 1 ? (unsigned)(b->team_qpad * (b->team + (pipe ? 1 : 0))) : (unsigned)b->Q);
+        hipLaunchKernelGGL(block_kernel_fn_of(b->team, pipe), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;
