@@ -1217,49 +1217,33 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         u64 rmp = PIPE ? (rk.pr & A_prev) : 0ull;
                         nnear += (uint32_t)__builtin_popcountll(rm) + (uint32_t)__builtin_popcountll(rmp);
                         while (rm | rmp) {
+                            // every lane's cheaper candidate among "its" sample of this block and of the previous one, then ONE
+                            // (cost, index) minimum over the wave; the lane that holds the minimum names the sample
                             double cn = f64_inf();
                             uint32_t ci = NONE;
+                            bool mine_prev = false;
                             if (rm & lbit) {
-                                cn = newcost[lane] + sqrt_u32(dk);
-                                ci = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & ltmask);
-                                if (!(cn < cnear)) {
-                                    cn = f64_inf();
-                                    ci = NONE;
+                                const double c = newcost[lane] + sqrt_u32(dk);
+                                if (c < cnear) {
+                                    cn = c;
+                                    ci = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & ltmask);
                                 }
                             }
-                            wave_min_f64_idx(cn, ci);
-                            bool from_prev = false;
-                            if (PIPE && rmp != 0) {
-                                double cp = f64_inf();
-                                uint32_t cip = NONE;
-                                if (rmp & lbit) {
-                                    cp = prevcost[lane] + sqrt_u32(dkp);
-                                    cip = (uint32_t)jp0 + (uint32_t)__builtin_popcountll(A_prev & ltmask);
-                                    if (!(cp < cnear)) {
-                                        cp = f64_inf();
-                                        cip = NONE;
-                                    }
-                                }
-                                wave_min_f64_idx(cp, cip);
-                                if (cip != NONE && (ci == NONE || key_lt(cp, cip, cn, ci))) {
-                                    cn = cp;
+                            if (PIPE && (rmp & lbit)) {
+                                const double c = prevcost[lane] + sqrt_u32(dkp);
+                                const uint32_t cip = (uint32_t)jp0 + (uint32_t)__builtin_popcountll(A_prev & ltmask);
+                                if (c < cnear && key_lt(c, cip, cn, ci)) {
+                                    cn = c;
                                     ci = cip;
-                                    from_prev = true;
+                                    mine_prev = true;
                                 }
                             }
+                            const uint32_t myci = ci;
+                            wave_min_f64_idx(cn, ci);
                             if (ci == NONE || !key_lt(cn, ci, pc, pi)) break;
-                            uint32_t kk = 0, axy;  // which sample is node ci
-                            if (from_prev) {
-                                u64 am = A_prev;
-                                for (uint32_t c = 0; c < ci - (uint32_t)jp0; ++c) am &= am - 1;
-                                kk = (uint32_t)__builtin_ctzll(am);
-                                axy = (uint32_t)__builtin_amdgcn_readlane((int)xop, (int)kk);
-                            } else {
-                                u64 am = acc_exact;
-                                for (uint32_t c = 0; c < ci - (uint32_t)j0; ++c) am &= am - 1;
-                                kk = (uint32_t)__builtin_ctzll(am);
-                                axy = (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk);
-                            }
+                            const uint32_t kk = (uint32_t)__builtin_ctzll(__ballot(myci == ci));  // node indices are unique
+                            const bool from_prev = __builtin_amdgcn_readlane((int)mine_prev, (int)kk) != 0;
+                            const uint32_t axy = (uint32_t)__builtin_amdgcn_readlane((int)(from_prev ? xop : xo), (int)kk);
                             int cc = 0;
                             const bool ok = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:519
                             ntests += 1;
