@@ -188,6 +188,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     __shared__ __attribute__((aligned(16))) unsigned long long statred[SB * 5];
     __shared__ uint32_t xq_lds[SB];
     __shared__ double newcost[SB];
+    struct ParRound {  // pipelined committer: the samples re-resolved side by side, one wave each
+        u64 acc_opt, aprev;
+        uint32_t list[NWAVE], acc[NWAVE];
+        uint32_t count;
+        int32_t jp0;
+    };
+    __shared__ __attribute__((aligned(16))) ParRound par;
     __shared__ uint32_t xqp_lds[PIPE ? 64 : 1];   // pipelined teams: the samples of the previous super-block ...
     __shared__ double prevcost[PIPE ? 64 : 1];    // ... and (committer) the exact costs of the nodes it inserted
     constexpr int WPS = NWAVE / BSM;  // waves per sample in the owner phase
@@ -1070,9 +1077,151 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             continue;
         }
 
-        // ---------------- C: commit (wave 0 of member 0) ----------------
+        // ---------------- C: commit (member 0; wave 0, one lane per sample) ----------------
+        // References to nodes the commit itself inserts are kept as sample references until the store pass knows every node
+        // index: 0x80000000 + kk = sample kk of the previous block (pipelined teams), 0x80000040 + kk = sample kk of this block.
+        // They compare like the node indices they stand for (above every snapshot index, previous block first, sample order).
+        BRec r;
+        r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnear = r.pad = 0;
+        r.nnmask = r.rmask = r.dupmask = r.pnn = r.pr = r.pdup = 0;
+        r.Vs = r.cbest = r.pc = 0.0;
+        const u64 lbit = 1ull << lane;
+        const u64 ltmask = lbit - 1ull;  // lanes below
+        bool acc0 = false, goalhit = false, remote_ok = true;
+        u64 harm = 0, pbad = 0, acc_exact = 0, fin = 0, fin_acc = 0;  // fin: samples already re-resolved (by the parallel round)
+        // harm: the earlier samples within r_rewire that, once inserted at their cost, would be tried as this sample's parent
+        // before the snapshot's choice: cost-through-it < cost through the snapshot parent (ties go to the lower index = the
+        // snapshot, rrt.py:518-521).  A single-precision bound settles almost every pair; bit k is re-evaluated when sample
+        // k's cost becomes exact.
+        auto harmful = [&](int kk) -> bool {
+            const uint32_t d2 = dist2(xq_lds[kk], xv);
+            const double nc = newcost[kk];
+            const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
+            if (low >= screen_of(r.cbest)) return false;
+            return nc + sqrt_u32(d2) < r.cbest;
+        };
+        // Sample k on its own, re-resolved against snapshot + inserted nodes of this block (accepted: acc_k) and of the previous
+        // one (ap, their count base jp): any wave.  Its record in LDS is replaced by the final one; returns acceptance and cost.
+        auto resolve_sample = [&](int k, u64 acc_k, u64 ap, int jp, bool check_full, bool &acc, double &cbest) {
+            const BRec rk = brec[k];
+            const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
+            uint32_t vn = rk.vs, d2n = rk.d2s;
+            double Vn = rk.Vs;
+            bool nocoll = (rk.los_s >> 31) != 0;
+            uint32_t cells = rk.los_s & 0x7fffffffu;
+            double pc = rk.pc;
+            uint32_t pi = (rk.pc < f64_inf()) ? rk.vbest : NONE, nnear = rk.nnear;
+            uint32_t ntests = rk.pstat >> 20, tcells = rk.pstat & 0xfffffu;
+            const uint32_t xo = (lane < SB) ? xq_lds[lane] : Xk;  // lane kk: sample kk
+            const uint32_t dk = dist2(xo, Xk);
+            // pipelined: lane kk also stands for sample kk of the previous block (inserted ones: ap, exact costs)
+            const uint32_t xop = PIPE ? xqp_lds[lane] : Xk;
+            const uint32_t dkp = dist2(xop, Xk);
+            const int snapj = PIPE ? jp : j0;  // the node count the sample's owner resolved it against
+            const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_k) != 0 || (PIPE && (rk.pdup & ap) != 0);
+            const u64 nm = rk.nnmask & acc_k;
+            const u64 pnm = PIPE ? (rk.pnn & ap) : 0ull;
+            bool nn_inblock = false;
+            if (nm | pnm) {  // nearest is an inserted block node: smallest distance, lowest node index on ties
+                uint32_t kd = (nm & lbit) ? dk : NONE, kk = (uint32_t)lane;
+                wave_min_key_idx(kd, kk);
+                uint32_t kdp = (pnm & lbit) ? dkp : NONE, kkp = (uint32_t)lane;
+                wave_min_key_idx(kdp, kkp);
+                nn_inblock = true;
+                uint32_t axy;
+                if (pnm != 0 && (nm == 0 || kdp <= kd)) {  // a node of the previous block (its indices are the lower ones)
+                    d2n = kdp;
+                    vn = 0x80000000u + kkp;
+                    Vn = prevcost[kkp];
+                    axy = (uint32_t)__builtin_amdgcn_readlane((int)xop, (int)kkp);
+                } else {
+                    d2n = kd;
+                    vn = 0x80000040u + kk;
+                    Vn = newcost[kk];
+                    axy = (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk);
+                }
+                int cc = 0;
+                nocoll = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:424
+                cells = (uint32_t)cc;
+            }
+            acc = nocoll && !dup && !(check_full && j0 + __builtin_popcountll(acc_k) == n);  // rrt.py:425
+            uint32_t vbest = vn;
+            cbest = Vn + sqrt_u32(d2n);
+            if (acc && star) {
+                const double cnear = cbest;
+                if (nn_inblock) {
+                    const double cnear_s = rk.Vs + sqrt_u32(rk.d2s);
+                    if (cnear > cnear_s) {  // entries between the two bounds were never priced: redo the snapshot part
+                        ntests = 0;
+                        tcells = 0;
+                        snapshot_parent(Xk, snapj, true, cnear, pc, pi, nnear, ntests, tcells);
+                    } else if (pi != NONE && !(pc < cnear)) {
+                        pc = f64_inf();
+                        pi = NONE;
+                    }
+                }
+                // inserted block nodes within r_rewire, in (cost, index) order, while they beat the snapshot's best
+                u64 rm = rk.rmask & acc_k;
+                u64 rmp = PIPE ? (rk.pr & ap) : 0ull;
+                nnear += (uint32_t)__builtin_popcountll(rm) + (uint32_t)__builtin_popcountll(rmp);
+                while (rm | rmp) {
+                    // every lane's cheaper candidate among "its" sample of this block and of the previous one, then ONE
+                    // (cost, reference) minimum over the wave
+                    double cn = f64_inf();
+                    uint32_t ci = NONE;
+                    if (rm & lbit) {
+                        const double c = newcost[lane] + sqrt_u32(dk);
+                        if (c < cnear) {
+                            cn = c;
+                            ci = 0x80000040u + (uint32_t)lane;
+                        }
+                    }
+                    if (PIPE && (rmp & lbit)) {
+                        const double c = prevcost[lane] + sqrt_u32(dkp);
+                        if (c < cnear && key_lt(c, 0x80000000u + (uint32_t)lane, cn, ci)) {
+                            cn = c;
+                            ci = 0x80000000u + (uint32_t)lane;
+                        }
+                    }
+                    wave_min_f64_idx(cn, ci);
+                    if (ci == NONE || !key_lt(cn, ci, pc, pi)) break;
+                    const uint32_t kk = ci & 63u;
+                    const bool from_prev = (ci & 0x40u) == 0;
+                    const uint32_t axy = (uint32_t)__builtin_amdgcn_readlane((int)(from_prev ? xop : xo), (int)kk);
+                    int cc = 0;
+                    const bool ok = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:519
+                    ntests += 1;
+                    tcells += (uint32_t)cc;
+                    if (ok) {
+                        pc = cn;
+                        pi = ci;
+                        break;
+                    }
+                    if (from_prev) rmp &= ~(1ull << kk);
+                    else rm &= ~(1ull << kk);
+                }
+                if (pi != NONE) {
+                    vbest = pi;
+                    cbest = pc;
+                }
+            }
+            if (lane == 0) {  // the final record of this sample (pad = 1: nnear already counts the block's nodes)
+                BRec f = rk;
+                f.vs = vn;
+                f.los_s = cells;
+                f.cbest = cbest;
+                f.vbest = vbest;
+                f.pstat = (ntests << 20) | (tcells & 0xfffffu);
+                f.nnear = nnear;
+                f.pad = 1;
+                brec[k] = f;
+                newcost[k] = cbest;
+            }
+        };
+
+        // ---- part A (wave 0): the records, the optimistic picture, and for a pipelined committer the samples that can be
+        //      re-resolved side by side ----
         if (wave == 0) {
-            bool remote_ok = true;
             if (G > 1) {  // the other members' records: poll the arrival flags, then loads that bypass the L1
                 remote_ok = team_wait_all(t_arrive, 1, PIPE ? G : G - 1, epoch, t_fail, lane);
                 if (remote_ok && (PIPE || lane >= BSM) && lane < nb) {
@@ -1083,56 +1232,103 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     brec[lane] = u.r;
                 }
             }
+            if (PIPE && lane == 0) par.count = 0;
             if (!remote_ok) {
                 if (lane == 0) blk.pad0 = 1;
             } else {
-            BRec r;
-            r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnear = r.pad = 0;
-            r.nnmask = r.rmask = r.dupmask = r.pnn = r.pr = r.pdup = 0;
-            r.Vs = r.cbest = r.pc = 0.0;
-            if (lane < nb) r = brec[lane];  // lane s: sample s
-            const bool acc0 = lane < nb && (r.los_s >> 31) != 0 && (r.flags & 1u) == 0;  // accepted if nothing in the block interferes
-            const bool goalhit = informed && lane < nb && dist2(xv, xg) < goal_d2;
-            const u64 lbit = 1ull << lane;
-            const u64 ltmask = lbit - 1ull;  // lanes below
-            u64 acc_exact = 0;
-            int cur = 0;
-            bool cut = false;
-            if (lane < nb) newcost[lane] = r.cbest;  // optimistic (snapshot-resolved) cost; exact once the sample has committed
-            // harm: the earlier samples within r_rewire that, once inserted at their cost, would be tried as this sample's parent
-            // before the snapshot's choice: cost-through-it < cost through the snapshot parent (ties go to the lower index = the
-            // snapshot, rrt.py:518-521).  A single-precision bound settles almost every pair; bit k is re-evaluated when sample
-            // k's cost becomes exact.
-            auto harmful = [&](int kk) -> bool {
-                const uint32_t d2 = dist2(xq_lds[kk], xv);
-                const double nc = newcost[kk];
-                const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
-                if (low >= screen_of(r.cbest)) return false;
-                return nc + sqrt_u32(d2) < r.cbest;
-            };
-            u64 harm = 0;
-            if (lane < nb && acc0) {
-                u64 rm = r.rmask;
-                while (rm) {
-                    const int kk = __builtin_ctzll(rm);
-                    rm &= rm - 1;
-                    if (harmful(kk)) harm |= 1ull << kk;
-                }
-            }
-            // pipelined: the nodes the previous block inserted are exact; the samples of this block were resolved without them
-            if (PIPE && epoch == 1) jp0 = j0;
-            u64 pbad = 0;  // inserted samples of the previous block that affect this sample
-            if (PIPE && lane < nb) {
-                pbad = (r.pnn | r.pdup) & A_prev;
-                if (acc0) {
-                    u64 rm = r.pr & A_prev;
+                if (lane < nb) r = brec[lane];  // lane s: sample s
+                acc0 = lane < nb && (r.los_s >> 31) != 0 && (r.flags & 1u) == 0;  // accepted if nothing in the block interferes
+                goalhit = informed && lane < nb && dist2(xv, xg) < goal_d2;
+                if (lane < nb) newcost[lane] = r.cbest;  // optimistic (snapshot-resolved) cost; exact once the sample has committed
+                if (lane < nb && acc0) {
+                    u64 rm = r.rmask;
                     while (rm) {
                         const int kk = __builtin_ctzll(rm);
                         rm &= rm - 1;
-                        const uint32_t d2 = dist2(xqp_lds[kk], xv);
-                        const double nc = prevcost[kk];
-                        const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
-                        if (low < screen_of(r.cbest) && nc + sqrt_u32(d2) < r.cbest) pbad |= 1ull << kk;
+                        if (harmful(kk)) harm |= 1ull << kk;
+                    }
+                }
+                // pipelined: the nodes the previous block inserted are exact; the samples of this block were resolved without them
+                if (PIPE && epoch == 1) jp0 = j0;
+                if (PIPE && lane < nb) {
+                    pbad = (r.pnn | r.pdup) & A_prev;  // inserted samples of the previous block that affect this sample
+                    if (acc0) {
+                        u64 rm = r.pr & A_prev;
+                        while (rm) {
+                            const int kk = __builtin_ctzll(rm);
+                            rm &= rm - 1;
+                            const uint32_t d2 = dist2(xqp_lds[kk], xv);
+                            const double nc = prevcost[kk];
+                            const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
+                            if (low < screen_of(r.cbest) && nc + sqrt_u32(d2) < r.cbest) pbad |= 1ull << kk;
+                        }
+                    }
+                }
+                if (PIPE) {
+                    // Which affected samples can be re-resolved at once, each by a wave of its own?  Those whose earlier interacting
+                    // samples all keep their snapshot result whatever happens: not affected themselves and (transitively) not
+                    // interacting with an affected one ("tainted").  Everything else goes through the ordered loop below.
+                    const u64 popt = __ballot(acc0);
+                    const u64 inter = (r.nnmask | r.dupmask | r.rmask) & ltmask;
+                    const bool slow0 = lane < nb && (((r.nnmask | r.dupmask | harm) & popt & ltmask) != 0 || pbad != 0);
+                    const u64 S0 = __ballot(slow0);
+                    u64 taint = S0;
+                    for (int it = 0; it < 6; ++it) {
+                        const u64 t2 = taint | __ballot(lane < nb && (inter & taint) != 0);
+                        if (t2 == taint) break;
+                        taint = t2;
+                        if (it == 5) taint = ~0ull;  // no fixed point yet: give up on the parallel round
+                    }
+                    u64 L0 = __ballot(slow0 && (inter & taint) == 0);
+                    if (L0 != 0 && j0 + __builtin_popcountll(popt) < n) {  // (not in the run's last block: `j != n` needs exact counts)
+                        uint32_t cnt = 0;
+                        while (L0 != 0 && cnt < (uint32_t)NWAVE) {
+                            const int k = __builtin_ctzll(L0);
+                            L0 &= L0 - 1;
+                            if (lane == 0) par.list[cnt] = (uint32_t)k;
+                            cnt++;
+                        }
+                        if (lane == 0) {
+                            par.count = cnt;
+                            par.acc_opt = popt;
+                            par.aprev = A_prev;
+                            par.jp0 = jp0;
+                        }
+                    }
+                }
+            }
+        }
+        if (PIPE) {  // the parallel round: wave w re-resolves sample par.list[w]
+            __syncthreads();
+            const uint32_t cnt = par.count;
+            if ((uint32_t)wave < cnt) {
+                const int k = (int)par.list[wave];
+                bool acc;
+                double cb;
+                resolve_sample(k, par.acc_opt & lowmask64(k), par.aprev, par.jp0, false, acc, cb);
+                if (lane == 0) par.acc[wave] = acc ? 1u : 0u;
+            }
+            __syncthreads();
+        }
+        // ---- part B (wave 0): decide in order, store, publish ----
+        if (wave == 0 && remote_ok) {
+            int cur = 0;
+            bool cut = false;
+            if (PIPE) {
+                const uint32_t cnt = par.count;
+                for (uint32_t w = 0; w < cnt; ++w) {  // the samples the parallel round settled: final, whatever the loop finds
+                    const int k = (int)par.list[w];
+                    fin |= 1ull << k;
+                    if (par.acc[w] != 0u) fin_acc |= 1ull << k;
+                }
+                if (fin != 0) {  // their costs are exact now: the later samples they are a candidate parent of look again
+                    u64 rm = r.rmask & fin & fin_acc;
+                    if (lane < nb && acc0) {
+                        while (rm) {
+                            const int kk = __builtin_ctzll(rm);
+                            rm &= rm - 1;
+                            harm = (harm & ~(1ull << kk)) | (harmful(kk) ? (1ull << kk) : 0ull);
+                        }
                     }
                 }
             }
@@ -1140,139 +1336,27 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             //      re-resolved on its own and its record in LDS replaced by the final one.  Nothing is stored to HBM yet: the
             //      decisions only read the snapshot and the block's samples. ----
             const double c_ell0 = c_ell;
+            const bool myacc0 = (fin & lbit) ? (fin_acc & lbit) != 0 : acc0;  // a settled sample's acceptance is known
             while (cur < nb && !cut) {
-                const u64 pend = __ballot(acc0 && lane >= cur);
+                const u64 pend = __ballot(myacc0 && lane >= cur);
                 const u64 Aopt = acc_exact | (pend & ltmask);  // exact below cur, optimistic in [cur, lane)
                 // A sample keeps its snapshot result unless an earlier inserted sample of the block is nearer than its nearest,
                 // sits on its cell, or (accepted samples only) is a harmful candidate parent.
-                const bool slow = lane >= cur && lane < nb && (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || pbad != 0 || (goalhit && acc0));
+                const bool slow = lane >= cur && lane < nb && (fin & lbit) == 0 &&
+                                  (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || pbad != 0 || (goalhit && acc0));
                 const unsigned long long bad = __ballot(slow);
                 const int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
                 acc_exact |= pend & lowmask64(k0) & ~lowmask64(cur);
                 cur = k0;
                 if (cur >= nb) break;
-                // ---- sample `cur` on its own: re-resolve against snapshot + inserted block nodes ----
+                // ---- sample `cur` on its own ----
                 {
                     const int k = cur;
                     const int jk = j0 + __builtin_popcountll(acc_exact);  // nodes when this sample is tried
-                    const BRec rk = brec[k];
                     const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
-                    uint32_t vn = rk.vs, d2n = rk.d2s;
-                    double Vn = rk.Vs;
-                    bool nocoll = (rk.los_s >> 31) != 0;
-                    uint32_t cells = rk.los_s & 0x7fffffffu;
-                    double pc = rk.pc;
-                    uint32_t pi = (rk.pc < f64_inf()) ? rk.vbest : NONE, nnear = rk.nnear;
-                    uint32_t ntests = rk.pstat >> 20, tcells = rk.pstat & 0xfffffu;
-                    const uint32_t xo = (lane < SB) ? xq_lds[lane] : Xk;  // lane kk: sample kk
-                    const uint32_t dk = dist2(xo, Xk);
-                    // pipelined: lane kk also stands for sample kk of the previous block (inserted ones: A_prev, exact costs)
-                    const uint32_t xop = PIPE ? xqp_lds[lane] : Xk;
-                    const uint32_t dkp = dist2(xop, Xk);
-                    const int snapj = PIPE ? jp0 : j0;  // the node count the sample's owner resolved it against
-                    const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_exact) != 0 || (PIPE && (rk.pdup & A_prev) != 0);
-                    const u64 nm = rk.nnmask & acc_exact;
-                    const u64 pnm = PIPE ? (rk.pnn & A_prev) : 0ull;
-                    bool nn_inblock = false;
-                    if (nm | pnm) {  // nearest is an inserted block node: smallest distance, lowest node index on ties
-                        uint32_t kd = (nm & lbit) ? dk : NONE, kk = (uint32_t)lane;
-                        wave_min_key_idx(kd, kk);
-                        uint32_t kdp = (pnm & lbit) ? dkp : NONE, kkp = (uint32_t)lane;
-                        wave_min_key_idx(kdp, kkp);
-                        nn_inblock = true;
-                        uint32_t axy;
-                        if (pnm != 0 && (nm == 0 || kdp <= kd)) {  // a node of the previous block (its indices are the lower ones)
-                            d2n = kdp;
-                            vn = (uint32_t)jp0 + (uint32_t)__builtin_popcountll(A_prev & lowmask64((int)kkp));
-                            Vn = prevcost[kkp];
-                            axy = (uint32_t)__builtin_amdgcn_readlane((int)xop, (int)kkp);
-                        } else {
-                            d2n = kd;
-                            vn = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & lowmask64((int)kk));
-                            Vn = newcost[kk];
-                            axy = (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk);
-                        }
-                        int cc = 0;
-                        nocoll = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:424
-                        cells = (uint32_t)cc;
-                    }
-                    const bool acc = nocoll && !dup && jk != n;  // rrt.py:425
-                    uint32_t vbest = vn;
-                    double cbest = Vn + sqrt_u32(d2n);
-                    if (acc && star) {
-                        const double cnear = cbest;
-                        if (nn_inblock) {
-                            const double cnear_s = rk.Vs + sqrt_u32(rk.d2s);
-                            if (cnear > cnear_s) {  // entries between the two bounds were never priced: redo the snapshot part
-                                ntests = 0;
-                                tcells = 0;
-                                snapshot_parent(Xk, snapj, true, cnear, pc, pi, nnear, ntests, tcells);
-                            } else if (pi != NONE && !(pc < cnear)) {
-                                pc = f64_inf();
-                                pi = NONE;
-                            }
-                        }
-                        // inserted block nodes within r_rewire, in (cost, index) order, while they beat the snapshot's best
-                        u64 rm = rk.rmask & acc_exact;
-                        u64 rmp = PIPE ? (rk.pr & A_prev) : 0ull;
-                        nnear += (uint32_t)__builtin_popcountll(rm) + (uint32_t)__builtin_popcountll(rmp);
-                        while (rm | rmp) {
-                            // every lane's cheaper candidate among "its" sample of this block and of the previous one, then ONE
-                            // (cost, index) minimum over the wave; the lane that holds the minimum names the sample
-                            double cn = f64_inf();
-                            uint32_t ci = NONE;
-                            bool mine_prev = false;
-                            if (rm & lbit) {
-                                const double c = newcost[lane] + sqrt_u32(dk);
-                                if (c < cnear) {
-                                    cn = c;
-                                    ci = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & ltmask);
-                                }
-                            }
-                            if (PIPE && (rmp & lbit)) {
-                                const double c = prevcost[lane] + sqrt_u32(dkp);
-                                const uint32_t cip = (uint32_t)jp0 + (uint32_t)__builtin_popcountll(A_prev & ltmask);
-                                if (c < cnear && key_lt(c, cip, cn, ci)) {
-                                    cn = c;
-                                    ci = cip;
-                                    mine_prev = true;
-                                }
-                            }
-                            const uint32_t myci = ci;
-                            wave_min_f64_idx(cn, ci);
-                            if (ci == NONE || !key_lt(cn, ci, pc, pi)) break;
-                            const uint32_t kk = (uint32_t)__builtin_ctzll(__ballot(myci == ci));  // node indices are unique
-                            const bool from_prev = __builtin_amdgcn_readlane((int)mine_prev, (int)kk) != 0;
-                            const uint32_t axy = (uint32_t)__builtin_amdgcn_readlane((int)(from_prev ? xop : xo), (int)kk);
-                            int cc = 0;
-                            const bool ok = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:519
-                            ntests += 1;
-                            tcells += (uint32_t)cc;
-                            if (ok) {
-                                pc = cn;
-                                pi = ci;
-                                break;
-                            }
-                            if (from_prev) rmp &= ~(1ull << kk);
-                            else rm &= ~(1ull << kk);
-                        }
-                        if (pi != NONE) {
-                            vbest = pi;
-                            cbest = pc;
-                        }
-                    }
-                    if (lane == 0) {  // the final record of this sample (pad = 1: nnear already counts the block's nodes)
-                        BRec f = rk;
-                        f.vs = vn;
-                        f.los_s = cells;
-                        f.cbest = cbest;
-                        f.vbest = vbest;
-                        f.pstat = (ntests << 20) | (tcells & 0xfffffu);
-                        f.nnear = nnear;
-                        f.pad = 1;
-                        brec[k] = f;
-                        newcost[k] = cbest;
-                    }
+                    bool acc;
+                    double cbest;
+                    resolve_sample(k, acc_exact, A_prev, jp0, true, acc, cbest);
                     if (acc) {
                         if (informed && dist2(Xk, xg) < goal_d2) {  // rrt.py:744-745
                             const bool first = nsoln == 0;
@@ -1296,7 +1380,16 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             {
                 if (j0 + __builtin_popcountll(acc_exact) > n) acc_exact &= ~(1ull << (63 - __builtin_clzll(acc_exact)));  // rrt.py:425 `j != n`: only the run's last sample
                 const bool inr = lane < cur;
-                const BRec f = inr ? brec[lane] : r;
+                BRec f = inr ? brec[lane] : r;
+                // sample references -> node indices, now that every acceptance is known
+                auto node_of = [&](uint32_t v) -> uint32_t {
+                    if (v == NONE || (v & 0x80000000u) == 0) return v;
+                    const int kk = (int)(v & 63u);
+                    return (v & 0x40u) ? (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & lowmask64(kk))
+                                       : (uint32_t)jp0 + (uint32_t)__builtin_popcountll(A_prev & lowmask64(kk));
+                };
+                f.vs = node_of(f.vs);
+                f.vbest = node_of(f.vbest);
                 const bool myacc = inr && ((acc_exact >> lane) & 1ull) != 0;
                 const int jmine = j0 + __builtin_popcountll(acc_exact & ltmask);  // j as this sample sees it
                 if (inr) {
@@ -1363,7 +1456,6 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the flag must not overtake the write-back
                 if (lane == 0) __hip_atomic_store(t_go, epoch, RRT_RLX_AGENT);
             }
-            }  // remote_ok
         }
         STAMP(4);
         __syncthreads();
