@@ -26,12 +26,14 @@ FLAG_LOGS = 1
 FLAG_SERIAL = 2
 FLAG_NOTEAM = 4
 FLAG_TEAM_FAULT = 8
+FLAG_NOPIPE = 16
 
 
-def kernel_flags(logs=False, serial=False, team=None, team_fault=False):
+def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=True):
     """flags word of rrt_plan / rrt_batch_create.  team: None = as many CUs per query as fit (up to 64), 1 = one CU,
-    2..64 = cap on the team size; team_fault = the fault-injection flag of the tests."""
-    f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_TEAM_FAULT if team_fault else 0)
+    2..64 = cap on the team size; pipe = False: teams of 8 and more do not pipeline super-blocks; team_fault = the
+    fault-injection flag of the tests."""
+    f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_TEAM_FAULT if team_fault else 0) | (0 if pipe else FLAG_NOPIPE)
     if team == 1:
         f |= FLAG_NOTEAM
     elif team is not None:
@@ -225,9 +227,9 @@ class Context:
         _check(self._h, lib().rrt_select_frame(self._h, int(k)))
 
     # ---- one-shot ----
-    def plan(self, query, n, logs=False, serial=False, team=None, team_fault=False):
+    def plan(self, query, n, logs=False, serial=False, team=None, team_fault=False, pipe=True):
         res = ResultArrays(n, logs)
-        flags = kernel_flags(logs, serial, team, team_fault)
+        flags = kernel_flags(logs, serial, team, team_fault, pipe)
         rc = lib().rrt_plan(self._h, C.byref(query), flags, C.byref(res.c))
         _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
         return rc, res
@@ -278,10 +280,11 @@ class Context:
 class Batch:
     """Q independent queries resident on the device (rrt_batch_*)."""
 
-    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False, team=None, team_fault: bool = False):
+    def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False, team=None, team_fault: bool = False,
+                 pipe: bool = True):
         self.ctx, self.Q, self.n_cap, self.logs = ctx, int(Q), int(n_cap), logs
         self._h = C.c_void_p()
-        flags = kernel_flags(logs, serial, team, team_fault)
+        flags = kernel_flags(logs, serial, team, team_fault, pipe)
         _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, flags, C.byref(self._h)))
         self._n = [0] * self.Q
 

@@ -143,12 +143,13 @@ def test_replan_chain_rng_continues_and_set_og(tag):
 
 
 # ------------------------------------------------------------------------------- device vs oracle, larger
-# teams of up to 64 CUs per query (default), capped teams (2 and 4: 16 samples per member; 16: 4 samples per member, 4 waves
-# per sample), one CU, one sample per iteration, and a team that loses a member (must finish on one CU per query)
-KERNELS = ["team", "team2", "team4", "team16", "block", "serial", "teamfault"]
+# teams of up to 64 CUs per query (default; 8 and more: pipelined super-blocks for RRTStandard / RRTStar), the same without the
+# pipeline, capped teams (2 and 4: 16 samples per member; 16: 4 samples per member, 4 waves per sample), one CU, one sample per
+# iteration, and a team that loses a member (must finish on one CU per query)
+KERNELS = ["team", "teamnp", "team2", "team4", "team16", "block", "serial", "teamfault"]
+_KERNEL_ARGS = {"team": {}, "teamnp": {"pipe": False}, "team2": {"team": 2}, "team4": {"team": 4}, "team16": {"team": 16},
+                "block": {"team": 1}, "serial": {"serial": True}, "teamfault": {"team": 8, "team_fault": True}}
 KERNELS_NOFAULT = [k for k in KERNELS if k != "teamfault"]
-_KERNEL_ARGS = {"team": {}, "team2": {"team": 2}, "team4": {"team": 4}, "team16": {"team": 16}, "block": {"team": 1},
-                "serial": {"serial": True}, "teamfault": {"team": 8, "team_fault": True}}
 
 
 def _oracle_vs_device(ctx, og8, alg, n, seed, xs, xg, r_rewire=None, r_goal=None, kernel="team"):
@@ -358,8 +359,8 @@ def test_every_team_size_gives_the_same_trees_every_time(gpu_ctx):
         samples = hostprep.draw_free_samples(np.random.default_rng(q), free, n)
         qs.append(_ffi.make_query(1, n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(64)))
     ref = None
-    for team in (None, 32, 16, 8, 4, 2, 1):
-        b = _ffi.Batch(gpu_ctx, Q, n, team=team)
+    for team, pipe in ((None, True), (None, False), (32, True), (16, True), (16, False), (8, True), (4, True), (2, True), (1, True)):
+        b = _ffi.Batch(gpu_ctx, Q, n, team=team, pipe=pipe)
         for q, (qu, keep) in enumerate(qs):
             b.set_query(q, qu)
         for rep in range(3):
@@ -374,8 +375,8 @@ def test_every_team_size_gives_the_same_trees_every_time(gpu_ctx):
             if ref is None:
                 ref = out
             for q in range(Q):
-                assert out[q][:3] == ref[q][:3], (team, rep, q)
-                assert all(np.array_equal(x, y) for x, y in zip(out[q][3:], ref[q][3:])), (team, rep, q)
+                assert out[q][:3] == ref[q][:3], (team, pipe, rep, q)
+                assert all(np.array_equal(x, y) for x, y in zip(out[q][3:], ref[q][3:])), (team, pipe, rep, q)
         assert b.team()[1] == 0
         b.close()
 

@@ -26,8 +26,8 @@ for q in range(a.queries):
                               Cmat=hostprep.rotation_to_world_frame(xs, xg)))
 ref = None
 bad = 0
-for team in (None, 32, 16, 8, 4, 2, 1):
-    b = _ffi.Batch(ctx, a.queries, a.n, team=team)
+for team, pipe in ((None, True), (None, False), (32, True), (16, True), (16, False), (8, True), (4, True), (2, True), (1, True)):
+    b = _ffi.Batch(ctx, a.queries, a.n, team=team, pipe=pipe)
     for q, (qu, keep) in enumerate(qs):
         b.set_query(q, qu)
     for rep in range(a.reps):
@@ -43,8 +43,8 @@ for team in (None, 32, 16, 8, 4, 2, 1):
             same = out[q][:3] == ref[q][:3] and all(np.array_equal(x, y) for x, y in zip(out[q][3:], ref[q][3:]))
             if not same:
                 bad += 1
-                print(f"MISMATCH team={team} rep={rep} query={q}: status/j/vgoal {out[q][:3]} vs {ref[q][:3]}")
-    print(f"team cap {team}: cus/query {b.team()[0]}, fallbacks {b.team()[1]}, {a.reps} repetitions, last kernel {b.elapsed_ms():.2f} ms")
+                print(f"MISMATCH team={team} pipe={pipe} rep={rep} query={q}: status/j/vgoal {out[q][:3]} vs {ref[q][:3]}")
+    print(f"team cap {team} pipe {pipe}: cus/query {b.team()[0]}, fallbacks {b.team()[1]}, {a.reps} repetitions, last kernel {b.elapsed_ms():.2f} ms")
     b.close()
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
