@@ -210,7 +210,8 @@ def main():
             "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {cfg['name']}", "queries_per_gpu": Q, "n": n,
                        "grid": [cfg["grid"], cfg["grid"]], "free_fraction": float((og == 0).mean()),
                        "iters_per_s": iters_total * args.steps / dt, "unfinished_queries": nbad,
-                       "cus_per_query": batch.team()[0], "team_fallbacks": batch.team()[1]},
+                       "cus_per_query": batch.team()[0] + (1 if batch.pipelined() else 0), "pipelined": batch.pipelined(),
+                       "team_fallbacks": batch.team()[1]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "rrt_expand_block_kernel", "kernel_ms": kern_avg_ms, "algorithmic_bytes_per_launch": int(bytes_local)},
@@ -274,6 +275,7 @@ def batched_leg(ctx, og, free, _ffi, hostprep):
     nodes = sum(r.c.j - 1 for r in res)
     by = sum(algorithmic_bytes(r.c) for r in res)
     cus, fallbacks = b.team()
+    cus += 1 if b.pipelined() else 0
     b.close()
     ach = by / (kms / steps * 1e-3) / 1e9
     return {"workload": "BASELINE.json configs[3] share of one GPU: " + cfg["name"], "value": nodes * steps / dt, "unit": "nodes/s",

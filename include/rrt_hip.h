@@ -112,6 +112,8 @@ int rrt_batch_launch(rrt_batch *b); /* asynchronous on the ctx stream; runs / re
 int rrt_batch_sync(rrt_batch *b);
 /* CUs working on each query (team size; 1 after a fallback) and how often a team hand-off timed out */
 int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fallbacks);
+/* 1 if the last launch ran the pipelined team kernel (one more CU per query, which only commits) */
+int rrt_batch_pipelined(rrt_batch *b, int32_t *pipelined);
 int rrt_batch_elapsed_ms(rrt_batch *b, float *ms); /* HIP events around the last launch's kernels */
 int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out);
 /* diagnostic builds (-DRRT_STAMPS): shader cycles wave 0 of query q spent in scan / barrier / nearest+line of sight /

@@ -46,7 +46,7 @@ def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=Tru
 SYMBOLS = (
     "rrt_ctx_create", "rrt_ctx_destroy", "rrt_last_error_string", "rrt_set_grid", "rrt_noise_grids", "rrt_select_frame",
     "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
-    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_elapsed_ms",
+    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_pipelined", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
     "rrt_plan", "rrt_plan_resume", "rrt_plan_batch",
     "rrt_prim_collisionfree", "rrt_prim_nearest_within", "rrt_prim_sqrt_u32", "rrt_prim_sqrt_u24", "rrt_prim_sqrt_f64",
@@ -109,6 +109,7 @@ def lib():
             "rrt_batch_launch": ([vp], C.c_int),
             "rrt_batch_sync": ([vp], C.c_int),
             "rrt_batch_team": ([vp, C.POINTER(i32), C.POINTER(i32)], C.c_int),
+            "rrt_batch_pipelined": ([vp, C.POINTER(i32)], C.c_int),
             "rrt_batch_elapsed_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
             "rrt_batch_get_result": ([vp, i32, C.POINTER(Result)], C.c_int),
             "rrt_batch_result_block": ([vp, C.POINTER(vp), C.POINTER(i64)], C.c_int),
@@ -321,6 +322,12 @@ class Batch:
         g, f = C.c_int32(0), C.c_int32(0)
         _check(self.ctx.handle, lib().rrt_batch_team(self._h, C.byref(g), C.byref(f)))
         return g.value, f.value
+
+    def pipelined(self):
+        """True if the last launch ran the pipelined team kernel"""
+        v = C.c_int32(0)
+        _check(self.ctx.handle, lib().rrt_batch_pipelined(self._h, C.byref(v)))
+        return bool(v.value)
 
     def elapsed_ms(self):
         ms = C.c_float(0)

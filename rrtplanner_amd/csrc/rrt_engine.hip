@@ -631,6 +631,12 @@ extern "C" int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fal
     return RRT_OK;
 }
 
+extern "C" int rrt_batch_pipelined(rrt_batch *b, int32_t *pipelined) {
+    if (!b || !pipelined) return fail(nullptr, RRT_E_ARG, "rrt_batch_pipelined: NULL");
+    *pipelined = (b->use_block && b->team > 1 && b->pipe) ? 1 : 0;
+    return RRT_OK;
+}
+
 extern "C" int rrt_batch_elapsed_ms(rrt_batch *b, float *ms) {
     if (!b || !ms) return fail(nullptr, RRT_E_ARG, "rrt_batch_elapsed_ms: NULL");
     if (!b->timed) return fail(b->ctx, RRT_E_ARG, "rrt_batch_elapsed_ms: nothing launched");
