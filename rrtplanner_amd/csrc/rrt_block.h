@@ -637,20 +637,73 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         }
     };
 
-    while (i < n) {
+    // An Informed query on a pipelined team: the workers resolve block s + 1 as if the commit of block s neither ends early nor
+    // changes the ellipse.  When it does (a better solution, 13 times in BASELINE config 3), its state says RESTART: the block
+    // in flight is void -- the committer takes its turn without committing anything -- and the workers start over from the
+    // true state.  A worker therefore never ends the loop on its own count: it leaves when a state says the run is over.
+    constexpr int32_t ST_FLAG_RESTART = 1, ST_FLAG_STOP = 2;
+    const bool pipe_inf = PIPE && informed;
+    bool prev_valid = true;   // worker: the previous block exists (its samples are in xqp_lds)
+    bool void_next = false;   // committer: the last commit ended early or changed the ellipse
+    auto publish_state = [&](uint32_t ep, int32_t flags) {  // wave 0 of member 0: state of block `ep`, then its go flag
+        if (lane == 0) {
+            BlkWords u;
+            u.b.i = i;
+            u.b.j = j;
+            u.b.nsoln = nsoln;
+            u.b.vbest_soln = vbest_soln;
+            u.b.pad0 = 0;
+            u.b.pad1 = flags;
+            u.b.cmin_soln = cmin_soln;
+            u.b.c_ell = c_ell;
+#pragma unroll
+            for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + (PIPE ? (size_t)(ep & 1u) * 8 : 0) + w, u.w[w], RRT_RLX_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // wave 0 made every store of the commit
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the flag must not overtake the write-back
+        if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
+    };
+    while ((pipe_inf && g > 0) || i < n) {
         const int i0 = i, j0 = j;
-        const int nb = (n - i0) < SB ? (n - i0) : SB;  // samples of this (super-)block; lane s of every wave: sample s
+        int nb = (n - i0) < SB ? (n - i0) : SB;  // samples of this (super-)block; lane s of every wave: sample s
         const bool ell = informed && nsoln > 0;
+        bool void_blk = false;  // worker of a pipelined Informed query: nothing it could resolve this turn
+        if (nb <= 0) {
+            nb = 0;
+            void_blk = true;
+        }
         // ---------------- sample coordinates of the block (rrt.py:421 / :502 / :695-701) ----------------
         if (ell) {
             if (i_switch == n) i_switch = i0;
             const int u0i = i0 - ub_offset;
             if (ub == nullptr || u0i < 0 || u0i + nb > ub_count) {
-                status = ST_NEED_UB;
-                break;
+                if (pipe_inf && g > 0) {  // the committer will say so: take the turn, learn the state
+                    nb = 0;
+                    void_blk = true;
+                } else {
+                    status = ST_NEED_UB;
+                    if (pipe_inf && wave == 0) publish_state(epoch + 1, ST_FLAG_STOP);
+                    break;
+                }
             }
         }
         ++epoch;
+        if (PIPE && g == 0 && void_next) {  // the block in flight was resolved for a state that no longer holds: a turn without a commit
+            if (wave == 0) {
+                const bool ok = team_wait_all(t_arrive, 1, G, epoch, t_fail, lane);
+                if (ok) publish_state(epoch, 0);
+                if (lane == 0) blk.pad0 = ok ? 0 : 1;
+            }
+            void_next = false;
+            A_prev = 0;
+            jp0 = j;
+            __syncthreads();
+            if (blk.pad0 != 0) {
+                team_failed = true;
+                break;
+            }
+            continue;
+        }
         uint32_t xv = 0;  // lane s < nb: sample s
         if (lane < nb) {
             if (ell) {
@@ -671,7 +724,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             }
         }
         if (!worker && t < SB) xq_lds[t] = xv;  // a pipelined team's committer: nothing to resolve
-        if (worker) {
+        if (worker && !void_blk) {
         uint32_t xs16[BSM];
 #pragma unroll
         for (int k = 0; k < BSM; ++k) {  // this member's samples [BSM wg, BSM (wg + 1))
@@ -844,7 +897,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 nnmask = __ballot(lane < sidx && dk < d2s);
                 rmask = __ballot(lane < sidx && star && dk < r2);
                 dupmask = __ballot(lane < sidx && xo == Xk);
-                if (PIPE && epoch >= 2) {  // ... and every sample of the previous block, which is being committed meanwhile
+                if (PIPE && epoch >= 2 && prev_valid) {  // ... and every sample of the previous block, which is being committed meanwhile
                     const uint32_t xop = xqp_lds[lane];
                     const uint32_t dp = dist2(xop, Xk);
                     pnn = __ballot(dp < d2s);
@@ -983,14 +1036,17 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         //                  take the nodes of the commit of block s - 1 and go on with block s + 1 ----------------
         if (PIPE && g > 0) {
             const bool more = i0 + nb < n;
+            const bool take = epoch >= 2 && (more || pipe_inf);  // there is a commit to take (an Informed worker always looks)
             if (wave == 0) {
-                const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[wg * BSM];
-                gu64 *dst = t_rec + (size_t)(epoch & 1u) * 64 * BREC_WORDS + (size_t)wg * BSM * BREC_WORDS;
-                for (int w = lane; w < BSM * BREC_WORDS; w += 64) __hip_atomic_store(dst + w, src[w], RRT_RLX_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
+                if (!void_blk) {
+                    const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[wg * BSM];
+                    gu64 *dst = t_rec + (size_t)(epoch & 1u) * 64 * BREC_WORDS + (size_t)wg * BSM * BREC_WORDS;
+                    for (int w = lane; w < BSM * BREC_WORDS; w += 64) __hip_atomic_store(dst + w, src[w], RRT_RLX_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
+                }
                 if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
                 bool ok = true;
-                if (epoch >= 2 && more) {
+                if (take) {
                     ok = team_wait(t_go, epoch - 1, t_fail);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
@@ -1003,10 +1059,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 team_failed = true;
                 break;
             }
-            if (epoch >= 2 && more) {
+            i = i0 + nb;
+            prev_valid = !void_blk;
+            if (take) {
                 BlkWords u;
 #pragma unroll
                 for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + (size_t)((epoch - 1) & 1u) * 8 + w, RRT_RLX_AGENT);
+                if (pipe_inf && ((u.b.pad1 & ST_FLAG_STOP) != 0 || u.b.i >= n)) break;  // the run is over (or waits for the host)
                 const int jn = u.b.j;
                 if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
                     const uint32_t Xn = nodes_g[j0 + t];
@@ -1014,8 +1073,33 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     if (star) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 j = jn;
+                if (pipe_inf) {
+                    nsoln = u.b.nsoln;
+                    vbest_soln = u.b.vbest_soln;
+                    cmin_soln = u.b.cmin_soln;
+                    c_ell = u.b.c_ell;
+                    if ((u.b.pad1 & ST_FLAG_RESTART) != 0) {
+                        // that commit ended early or moved the ellipse: the block just handed over is void; wait for the
+                        // committer's empty turn, then start over from the true state without a previous block
+                        __syncthreads();  // (every wave has read blk.pad0)
+                        if (wave == 0) {
+                            const bool ok2 = team_wait(t_go, epoch, t_fail);
+                            if (lane == 0) blk.pad0 = ok2 ? 0 : 1;
+                        }
+                        __syncthreads();
+                        if (blk.pad0 != 0) {
+                            team_failed = true;
+                            break;
+                        }
+                        BlkWords u2;
+#pragma unroll
+                        for (int w = 0; w < 5; ++w) u2.w[w] = __hip_atomic_load(t_state + (size_t)(epoch & 1u) * 8 + w, RRT_RLX_AGENT);
+                        if ((u2.b.pad1 & ST_FLAG_STOP) != 0) break;
+                        i = u.b.i;
+                        prev_valid = false;
+                    }
+                }
             }
-            i = i0 + nb;
             __syncthreads();
             continue;
         }
@@ -1279,7 +1363,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         taint = t2;
                         if (it == 5) taint = ~0ull;  // no fixed point yet: give up on the parallel round
                     }
-                    u64 L0 = __ballot(slow0 && (inter & taint) == 0);
+                    u64 L0 = __ballot(slow0 && !goalhit && (inter & taint) == 0);  // (a goal hit ends or cuts the block: ordered loop)
                     if (L0 != 0 && j0 + __builtin_popcountll(popt) < n) {  // (not in the run's last block: `j != n` needs exact counts)
                         uint32_t cnt = 0;
                         while (L0 != 0 && cnt < (uint32_t)NWAVE) {
@@ -1440,22 +1524,14 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 b.j = j;
                 b.nsoln = nsoln;
                 b.vbest_soln = vbest_soln;
-                b.pad0 = b.pad1 = 0;
+                b.pad0 = 0;
+                b.pad1 = (PIPE && cut) ? ST_FLAG_RESTART : 0;
                 b.cmin_soln = cmin_soln;
                 b.c_ell = c_ell;
                 blk = b;
-                if (G > 1) {  // state first (write-through), then everything the commit stored, then the flag
-                    BlkWords u;
-                    u.b = b;
-#pragma unroll
-                    for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + (PIPE ? (size_t)(epoch & 1u) * 8 : 0) + w, u.w[w], RRT_RLX_AGENT);
-                }
             }
-            if (G > 1) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // wave 0 made every store of the commit
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the flag must not overtake the write-back
-                if (lane == 0) __hip_atomic_store(t_go, epoch, RRT_RLX_AGENT);
-            }
+            // state first (write-through), then everything the commit stored, then the flag
+            if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0);
         }
         STAMP(4);
         __syncthreads();
@@ -1465,6 +1541,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 team_failed = true;
                 break;
             }
+            void_next = PIPE && (b.pad1 & ST_FLAG_RESTART) != 0;
             i = b.i;
             j = b.j;
             nsoln = b.nsoln;

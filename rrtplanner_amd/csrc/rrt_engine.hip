@@ -566,12 +566,13 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
     if (b->use_block) {
         v.lds_chunks = b->blk_lds_chunks;
-        // a two-deep pipeline of super-blocks (one more workgroup per team, which only commits) for teams of 8 and more whose
-        // queries are all RRTStandard / RRTStar (an Informed block can end early or change the samples of the next one)
+        // a two-deep pipeline of super-blocks (one more workgroup per team, which only commits) for teams of 8 and more
         bool pipe = b->team >= 8 && !(b->flags & RRT_FLAG_NOPIPE) && b->team_qpad * (b->team + 1) <= ctx->num_cu;
         if (const char *e = getenv("RRT_PIPE")) pipe = pipe && atoi(e) != 0;
-        for (const auto &d : b->h_desc)
-            if (d.status == ST_RUNNING && d.alg == 2) pipe = false;
+        if (const char *e = getenv("RRT_PIPE_INFORMED"))  // experiments: Informed queries on the unpipelined team
+            if (atoi(e) == 0)
+                for (const auto &d : b->h_desc)
+                    if (d.status == ST_RUNNING && d.alg == 2) pipe = false;
         b->pipe = pipe;
         HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(b->team, pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);

@@ -311,6 +311,55 @@ def test_batch_of_queries_matches_single_queries(gpu_ctx):
     b.close()
 
 
+def test_pipelined_informed_batch_has_no_timeouts(gpu_ctx):
+    """Informed queries on pipelined teams (blocks in flight are voided when a commit moves the ellipse): the staged API with the
+    host's unit-ball hand-over, no hand-off may time out, trees equal the oracle's."""
+    og = perlin_occupancygrid(512, 512, seed=2)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    sg = np.random.default_rng(21)
+    Q, n, rr, rg = 3, 7000, 48, 10
+    b = _ffi.Batch(gpu_ctx, Q, n)
+    qs = []
+    for q in range(Q):
+        xs, xg = random_connected_pair(og, sg)
+        rng = np.random.default_rng(300 + q)
+        st0 = rng.bit_generator.state
+        samples = hostprep.draw_free_samples(rng, free, n)
+        Cm = hostprep.rotation_to_world_frame(xs, xg)
+        qu, keep = _ffi.make_query(2, n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(rr), goal_d2=hostprep.goal_threshold(rg), Cmat=Cm)
+        b.set_query(q, qu)
+        qs.append((xs, xg, samples, Cm, rng, st0, keep))
+    b.launch()
+    b.sync()
+    assert b.pipelined()
+    ubs = {}
+    for q in range(Q):
+        r = b.get_result(q, arrays=False)
+        if r.c.status == _ffi.RRT_NEED_UNITBALL:
+            xs, xg, samples, Cm, rng, st0, keep = qs[q]
+            rng.bit_generator.state = st0
+            hostprep.draw_free_samples(rng, free, r.c.i_switch)
+            ubs[q] = (hostprep.draw_unitball(rng, n - r.c.i_switch), r.c.i_switch)
+            b.set_unitball(q, ubs[q][0], ubs[q][1])
+    assert ubs  # at least one query reached its goal region
+    b.launch()
+    b.sync()
+    assert b.team()[1] == 0
+    for q in range(Q):
+        xs, xg, samples, Cm, rng, st0, keep = qs[q]
+        res = b.get_result(q)
+        kw = dict(unitball=ubs[q][0], ub_offset=ubs[q][1]) if q in ubs else {}
+        st, ro = oracle.plan(og8, n, 2, xs, xg, samples, r2_rewire=hostprep.radius_threshold(rr), r_goal=rg, Cmat=Cm, **kw)
+        live = ro.j + (1 if ro.found else 0)
+        assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal and res.i_switch == ro.i_switch
+        assert np.array_equal(res.pts[:live], ro.pts[:live])
+        assert np.array_equal(res.parent[:live], ro.parent[:live])
+        assert np.array_equal(res.vcost[:live], ro.vcost[:live])
+    b.close()
+
+
 def test_team_that_loses_a_member_finishes_on_one_cu_per_query(gpu_ctx):
     """RRT_FLAG_TEAM_FAULT: member 1 of every team leaves at once, so a hand-off of the others times out (bounded wait); the
     batch must notice, continue from the consistent block boundary with one CU per query, and give the oracle's trees."""
