@@ -175,7 +175,8 @@ union BlkWords {
 // while block s is committed the workers already resolve block s + 1 against the tree as it stood BEFORE block s; every
 // record then also carries the three interaction masks against the samples of block s, and the commit of block s + 1 treats
 // the nodes block s inserted like inserted samples of its own block (their acceptance and costs are exact by then).
-template <int G, int BSM, bool PIPE>
+// INF: the batch may hold Informed queries (alg 2); without it everything the ellipse needs is compiled out.
+template <int G, int BSM, bool PIPE, bool INF>
 __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM <= BS && BSM * G <= 64, "team size");
     static_assert(!PIPE || G > 1, "a pipeline needs a team");
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 
     // ---- per-query views ----
     const int n = D->n, alg = D->alg;
-    const bool star = alg >= 1, informed = alg == 2;
+    const bool star = alg >= 1, informed = INF && alg == 2;
     const uint32_t *samples = bv.samples + (size_t)q * bv.n_cap;
     uint32_t *nodes_g = bv.nodes + (size_t)q * bv.node_stride;
     const u32x4 *nodes_g4 = reinterpret_cast<const u32x4 *>(nodes_g);

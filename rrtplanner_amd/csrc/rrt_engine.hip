@@ -64,7 +64,7 @@ struct rrt_batch {
     std::vector<uint32_t> stage;  // host staging for packed samples
 };
 
-static const void *block_kernel_of(int team, bool pipe = false);
+static const void *block_kernel_of(int team, bool pipe, bool inf);
 static size_t block_kernel_static_lds(int team);
 
 static int fail(rrt_ctx *ctx, int code, const char *fmt, ...) {
@@ -519,36 +519,42 @@ static BatchView make_view(rrt_batch *b) {
 
 typedef void (*block_kernel_fn)(BatchView);
 
-static block_kernel_fn block_kernel_fn_of(int team, bool pipe) {
+template <bool INF>
+static block_kernel_fn block_kernel_fn_inf(int team, bool pipe) {
     if (pipe) {
         switch (team) {
-            case 64: return rrt_expand_block_kernel<64, 1, true>;
-            case 32: return rrt_expand_block_kernel<32, 2, true>;
-            case 16: return rrt_expand_block_kernel<16, 4, true>;
-            default: return rrt_expand_block_kernel<8, 8, true>;
+            case 64: return rrt_expand_block_kernel<64, 1, true, INF>;
+            case 32: return rrt_expand_block_kernel<32, 2, true, INF>;
+            case 16: return rrt_expand_block_kernel<16, 4, true, INF>;
+            default: return rrt_expand_block_kernel<8, 8, true, INF>;
         }
     }
     switch (team) {
-        case 64: return rrt_expand_block_kernel<64, 1, false>;
-        case 32: return rrt_expand_block_kernel<32, 2, false>;
-        case 16: return rrt_expand_block_kernel<16, 4, false>;
-        case 8: return rrt_expand_block_kernel<8, 8, false>;
-        case 4: return rrt_expand_block_kernel<4, 16, false>;
-        case 2: return rrt_expand_block_kernel<2, 16, false>;
-        default: return rrt_expand_block_kernel<1, 16, false>;
+        case 64: return rrt_expand_block_kernel<64, 1, false, INF>;
+        case 32: return rrt_expand_block_kernel<32, 2, false, INF>;
+        case 16: return rrt_expand_block_kernel<16, 4, false, INF>;
+        case 8: return rrt_expand_block_kernel<8, 8, false, INF>;
+        case 4: return rrt_expand_block_kernel<4, 16, false, INF>;
+        case 2: return rrt_expand_block_kernel<2, 16, false, INF>;
+        default: return rrt_expand_block_kernel<1, 16, false, INF>;
     }
 }
 
-static const void *block_kernel_of(int team, bool pipe) { return reinterpret_cast<const void *>(block_kernel_fn_of(team, pipe)); }
+static block_kernel_fn block_kernel_fn_of(int team, bool pipe, bool inf) {
+    return inf ? block_kernel_fn_inf<true>(team, pipe) : block_kernel_fn_inf<false>(team, pipe);
+}
+
+static const void *block_kernel_of(int team, bool pipe, bool inf) { return reinterpret_cast<const void *>(block_kernel_fn_of(team, pipe, inf)); }
 
 static size_t block_kernel_static_lds(int team) {
     hipFuncAttributes a{};
     size_t worst = 0;
-    for (bool pipe : {false, true}) {
-        if (pipe && team < 8) continue;
-        if (hipFuncGetAttributes(&a, block_kernel_of(team, pipe)) != hipSuccess) return 16384;
-        worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
-    }
+    for (bool pipe : {false, true})
+        for (bool inf : {false, true}) {
+            if (pipe && team < 8) continue;
+            if (hipFuncGetAttributes(&a, block_kernel_of(team, pipe, inf)) != hipSuccess) return 16384;
+            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+        }
     return (worst + 255) & ~(size_t)255;
 }
 
@@ -574,12 +580,15 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
                 for (const auto &d : b->h_desc)
                     if (d.status == ST_RUNNING && d.alg == 2) pipe = false;
         b->pipe = pipe;
-        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(b->team, pipe), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
+        bool inf = false;  // any Informed query in this launch?
+        for (const auto &d : b->h_desc)
+            if (d.status == ST_RUNNING && d.alg == 2) inf = true;
+        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(b->team, pipe, inf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         if (b->team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
         const dim3 tg(b->team > 1 ? (unsigned)(b->team_qpad * (b->team + (pipe ? 1 : 0))) : (unsigned)b->Q);
-        hipLaunchKernelGGL(block_kernel_fn_of(b->team, pipe), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        hipLaunchKernelGGL(block_kernel_fn_of(b->team, pipe, inf), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;
