@@ -29,23 +29,26 @@
 
 namespace rrtdev {
 
-constexpr int BS = 16;  // samples one workgroup resolves per pass (one owner wave each): 16 alone or in a team of up to 4, 8 / 4 in a team of 8 / 16
+constexpr int BS = 16;  // most samples one workgroup resolves per pass (see BSM below)
 constexpr int CG = 2;   // cells whose records an owner streams concurrently
 
 // ---- teams: G workgroups (CUs) on one query ---------------------------------------------------------------------
 // A single query is a chain of inserts, but the expensive parts of a block -- scan and owner phase -- only read the
-// snapshot.  A team of G workgroups therefore takes a super-block of 16*G samples: member g scans and resolves samples
-// [16g, 16g+16) on its own CU (own LDS copy of the node cache and of the cell fill counts), hands its 16 records to
-// member 0, whose wave 0 commits all 16*G samples in order (one lane per sample) and publishes the new state; every
-// member then appends the new nodes to its LDS copies.  Two hand-offs per super-block:
-//   records   member g>0 -> member 0: owners leave their record in LDS; after the workgroup barrier ONE wave writes the 16
-//             records write-through (agent-scope stores, whole 128-byte lines), drains, and stores the member's arrival
-//             flag; wave 0 of member 0 polls the flags and reads the records with agent-scope loads (they bypass its L1)
+// snapshot.  A team of G workgroups therefore takes a super-block of up to 64 samples: member g scans and resolves BSM of
+// them on its own CU (own LDS copy of the node cache and of the cell fill counts; BSM = 16 with one wave per sample for
+// G <= 4, else 64 / G with a group of 16 / BSM waves per sample), hands its records to member 0, whose wave 0 commits all
+// samples in order (one lane per sample) and publishes the new state; every member then appends the new nodes to its LDS
+// copies.  Two hand-offs per super-block:
+//   records   member g>0 -> member 0: owners leave their record in LDS; after the workgroup barrier ONE wave writes the
+//             member's records write-through (agent-scope stores), drains, and stores the member's arrival flag; wave 0 of
+//             member 0 polls the flags and reads the records with agent-scope loads (they bypass its L1)
 //   commit    member 0 -> members g>0: plain stores (nodes, costs, parents, cell records, bitmap), agent release,
 //             s_waitcnt, flag; a member polls the flag with one wave, runs ONE agent acquire (drops its L1), waits for it,
 //             joins the workgroup barrier, and only then the workgroup loads.
-// All members must be resident together (the launch keeps teams x G <= CUs); every spin is bounded by a wall-clock
-// limit that fails the query (status ST_TEAM_FAIL) instead of hanging the device.
+// Teams of 8 and more are pipelined (template parameter PIPE below): one more workgroup that only commits, the workers one
+// block ahead of it.  All members must be resident together (the launch keeps teams x members <= CUs); every spin is bounded
+// by a wall-clock limit that fails the query (status ST_TEAM_FAIL, the host then continues it with one CU) instead of
+// hanging the device.
 constexpr int TEAM_MAX = 64;
 constexpr int TEAM_BYTES = 24576;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
 constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 2 x 64 */, TEAM_OFF_REC = 512 /* 2 x 6656 */, TEAM_OFF_ARRIVE = 13824 /* 65 x 128 */;
