@@ -319,7 +319,8 @@ def test_pipelined_informed_batch_has_no_timeouts(gpu_ctx):
     gpu_ctx.set_grid(og8)
     free = np.argwhere(og8 == 0)
     sg = np.random.default_rng(21)
-    Q, n, rr, rg = 3, 7000, 48, 10
+    algs = [2, 1, 2, 0, 2, 1]  # a mixed batch: the Informed-capable kernel also runs the RRTStandard / RRTStar queries
+    Q, n, rr, rg = len(algs), 7000, 48, 10
     b = _ffi.Batch(gpu_ctx, Q, n)
     qs = []
     for q in range(Q):
@@ -328,7 +329,8 @@ def test_pipelined_informed_batch_has_no_timeouts(gpu_ctx):
         st0 = rng.bit_generator.state
         samples = hostprep.draw_free_samples(rng, free, n)
         Cm = hostprep.rotation_to_world_frame(xs, xg)
-        qu, keep = _ffi.make_query(2, n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(rr), goal_d2=hostprep.goal_threshold(rg), Cmat=Cm)
+        qu, keep = _ffi.make_query(algs[q], n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(rr) if algs[q] else 0,
+                                   goal_d2=hostprep.goal_threshold(rg), Cmat=Cm)
         b.set_query(q, qu)
         qs.append((xs, xg, samples, Cm, rng, st0, keep))
     b.launch()
@@ -351,7 +353,7 @@ def test_pipelined_informed_batch_has_no_timeouts(gpu_ctx):
         xs, xg, samples, Cm, rng, st0, keep = qs[q]
         res = b.get_result(q)
         kw = dict(unitball=ubs[q][0], ub_offset=ubs[q][1]) if q in ubs else {}
-        st, ro = oracle.plan(og8, n, 2, xs, xg, samples, r2_rewire=hostprep.radius_threshold(rr), r_goal=rg, Cmat=Cm, **kw)
+        st, ro = oracle.plan(og8, n, algs[q], xs, xg, samples, r2_rewire=hostprep.radius_threshold(rr) if algs[q] else 0, r_goal=rg, Cmat=Cm, **kw)
         live = ro.j + (1 if ro.found else 0)
         assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal and res.i_switch == ro.i_switch
         assert np.array_equal(res.pts[:live], ro.pts[:live])
