@@ -333,6 +333,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         if (const char *e = getenv("RRT_TEAM")) want = atoi(e);  // experiments: cap the team size
         b->team = 1;
         b->team_qpad = (Q + 7) & ~7;
+        int pipe_team = 0, pipe_stride = 0;  // the largest team of 8+ that also has room for its committer (pipelined)
         for (int g : {2, 4, 8, 16, 32, 64}) {
             const int step = g <= 16 ? 8 : (g == 32 ? 4 : 2);
             int stride = ((Q + step - 1) / step) * step;
@@ -342,6 +343,15 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
                 b->team = g;
                 b->team_qpad = stride;
             }
+            if (g >= 8 && g <= want && !(flags & RRT_FLAG_NOPIPE) && stride * (g + 1) <= ctx->num_cu) {
+                pipe_team = g;
+                pipe_stride = stride;
+            }
+        }
+        // a pipelined team beats an unpipelined one of twice its size (config 2: 8+1 CUs 24.7 ms vs 16 CUs 27.3 ms, ...)
+        if (pipe_team != 0 && b->team <= 2 * pipe_team) {
+            b->team = pipe_team;
+            b->team_qpad = pipe_stride;
         }
     }
     b->spill_stride = chunks * CHUNK * (b->team + 1);  // per member (and a pipelined team's committer): 256 parked entries per wave and node chunk; also go2goal's cost array
