@@ -5,6 +5,7 @@ is visible, the functions here raise.  The library is built in-tree by
 ``__graft_entry__.build()`` / ``make -C rrtplanner_amd/csrc``.
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -195,6 +196,8 @@ class Context:
         return self._h
 
     def close(self):
+        for b in list(getattr(self, "_batches", ())):  # batches hold a pointer to the context: they go first
+            b.close()
         if self._h:
             lib().rrt_ctx_destroy(self._h)
             self._h = C.c_void_p()
@@ -287,6 +290,9 @@ class Batch:
         self._h = C.c_void_p()
         flags = kernel_flags(logs, serial, team, team_fault, pipe)
         _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, flags, C.byref(self._h)))
+        if not hasattr(ctx, "_batches"):
+            ctx._batches = weakref.WeakSet()
+        ctx._batches.add(self)
         self._n = [0] * self.Q
 
     def close(self):

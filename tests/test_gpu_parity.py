@@ -524,3 +524,14 @@ def test_custom_costfn_is_rejected_not_emulated():
     p = amd.RRTStar(og, 10, 5, costfn=lambda vc, pts, v, x: vc[v] + 1.0, pbar=False)
     with pytest.raises(NotImplementedError):
         p.plan(np.array([1, 1]), np.array([5, 5]))
+
+
+def test_context_close_takes_its_batches_along():
+    """Closing a context first closes the batches created on it (they hold a pointer to it); closing them again is harmless."""
+    ctx = _ffi.Context(0)
+    ctx.set_grid(np.zeros((32, 32), dtype=np.uint8))
+    b1, b2 = _ffi.Batch(ctx, 2, 100), _ffi.Batch(ctx, 1, 50, team=1)
+    ctx.close()
+    b1.close()
+    b2.close()
+    del b1, b2, ctx
