@@ -86,7 +86,7 @@ typedef struct rrt_result {
 
 /* ---- context / grid -------------------------------------------------------------- */
 int rrt_ctx_create(int32_t device_id, rrt_ctx **out);
-int rrt_ctx_destroy(rrt_ctx *ctx);
+int rrt_ctx_destroy(rrt_ctx *ctx); /* destroy the batches created on a context before the context itself */
 const char *rrt_last_error_string(rrt_ctx *ctx); /* ctx may be NULL */
 /* RRT.__init__ / set_og (rrt.py:64-65, :261-272): og_nonzero is (W,H) C-order, 1 = obstacle. */
 int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, int32_t H);
