@@ -161,6 +161,7 @@ def main():
         one_step()
         if use_dist:
             gathered = multi.gather_result_blocks(gather_buf)
+            torch.cuda.current_stream().synchronize()
     sync_all()
     t0 = time.perf_counter()
     kern_ms = 0.0
@@ -168,6 +169,7 @@ def main():
         kern_ms += one_step()
         if use_dist:
             gathered = multi.gather_result_blocks(gather_buf)
+            torch.cuda.current_stream().synchronize()  # the next step rewrites the slab the collective is reading
     sync_all()
     dt = time.perf_counter() - t0
     if gathered is not None and rank == 0:  # sanity of the collective: rank 0's own slab must come back unchanged
