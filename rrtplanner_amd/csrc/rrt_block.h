@@ -51,7 +51,7 @@ constexpr int CG = 2;   // cells whose records an owner streams concurrently
 // hanging the device.
 constexpr int TEAM_MAX = 64;
 constexpr int TEAM_BYTES = 24576;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
-constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 2 x 64 */, TEAM_OFF_REC = 512 /* 2 x 6656 */, TEAM_OFF_ARRIVE = 13824 /* 65 x 128 */;
+constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 2 x 64 */, TEAM_OFF_REC = 512 /* 2 x 6656 */, TEAM_OFF_ARRIVE = 13824 /* 65 x 128 */, TEAM_OFF_RES = 22144 /* 65 x 16 */;
 constexpr unsigned long long TEAM_TIMEOUT_TICKS = 50000000ull;  // 0.5 s of the 100 MHz wall clock
 
 typedef unsigned long long u64;
@@ -1555,31 +1555,106 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         }
     }
 
-    if (G > 1 && g > 0) return;  // member 0 finishes the query (its copies of the state are the committed ones)
-    if (team_failed) status = ST_TEAM_FAIL;
+    // ---------------- the end of the run: member 0 finishes the query; a team shares go2goal ----------------
+    constexpr uint32_t FINAL = 0x40000000u;   // "epoch" of the final hand-offs, above every block's
+    constexpr int NWG = G + (PIPE ? 1 : 0);   // workgroups of the team
+    if (team_failed) {
+        if (G > 1 && g > 0) return;
+        status = ST_TEAM_FAIL;
+    }
+    if (G > 1 && g > 0) {
+        // the members wait for the final tree (a pipelined worker left the loop ahead of the last commits)
+        if (wave == 0) {
+            const bool ok = team_wait(t_go, FINAL, t_fail);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) blk.pad0 = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (blk.pad0 != 0) return;
+        BlkWords u;
+#pragma unroll
+        for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + w, RRT_RLX_AGENT);  // FINAL is even: slot 0
+        if ((u.b.pad1 & ST_FLAG_STOP) != 0) return;  // no goal connection this launch (the host has to supply data, or a failure)
+        j = u.b.j;
+    } else if (G > 1 && status != ST_TEAM_FAIL) {
+        if (wave == 0) publish_state(FINAL, status == ST_RUNNING ? 0 : ST_FLAG_STOP);
+    }
 
     // cell fill counts back to HBM (a resumed launch reloads them); fold wave 0's statistics
-    for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
+    if (g == 0) {
+        for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
+    }
     __syncthreads();
 
-    // ---------------- go2goal (rrt.py:311-332): same branch and bound as rrt_expand_kernel ----------------
+    // ---------------- go2goal (rrt.py:311-332): the first node in (cost-to-goal, index) order with a free line of sight.  Every
+    //                  workgroup of the team answers for the nodes g, g + NWG, g + 2 NWG, ...; member 0 takes the minimum ----------------
     int vgoal = 0, found = 0;
     if (status == ST_RUNNING) {
         status = ST_DONE;
         double pc;
         uint32_t pi;
-        go2goal_phase(og, H, nodes_g, vcost, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)smem, bslots, t, lane, wave, pc, pi);
-        if (pi != NONE) {
-            found = 1;
-            vgoal = j;  // rrt.py:319
-            if (t == 0) {
-                nodes_g[j] = xg;
-                vcost[j] = pc;
-                parent[j] = (int32_t)pi;
+        const int cnt = j > g ? (j - g + NWG - 1) / NWG : 0;
+        go2goal_phase(og, H, nodes_g, vcost, g, NWG, cnt, xg, reinterpret_cast<uint32_t *>(clist_base), (RRT_LDS uint32_t *)smem, bslots, t, lane,
+                      wave, pc, pi);
+        if (G > 1) {
+            gu64 *const t_res = (gu64 *)(tb + TEAM_OFF_RES);
+            if (g > 0) {
+                if (wave == 0) {
+                    if (lane == 0) {
+                        __hip_atomic_store(t_res + 2 * g, (u64)__double_as_longlong(pc), RRT_RLX_AGENT);
+                        __hip_atomic_store(t_res + 2 * g + 1, (u64)pi, RRT_RLX_AGENT);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, FINAL, RRT_RLX_AGENT);
+                }
+                return;
             }
-        } else {
-            if (j < n) status = ST_UNREACHABLE;
-            vgoal = 0;  // rrt.py:330-331
+            if (wave == 0) {
+                const bool ok = team_wait_all(t_arrive, 1, NWG - 1, FINAL, t_fail, lane);
+                double c = f64_inf();
+                uint32_t ci = NONE;
+                if (ok && lane < NWG - 1) {
+                    c = __longlong_as_double((long long)__hip_atomic_load(t_res + 2 * (lane + 1), RRT_RLX_AGENT));
+                    ci = (uint32_t)__hip_atomic_load(t_res + 2 * (lane + 1) + 1, RRT_RLX_AGENT);
+                }
+                if (lane == 63 && key_lt(pc, pi, c, ci)) {  // (NWG - 1 <= 64 members in lanes 0..NWG-2; this workgroup's own answer: lane 63 ...
+                    c = pc;
+                    ci = pi;
+                }
+                if (NWG - 1 == 64) {  // ... unless all 64 lanes are taken: fold it in after the reduction)
+                    wave_min_f64_idx(c, ci);
+                    if (key_lt(pc, pi, c, ci)) {
+                        c = pc;
+                        ci = pi;
+                    }
+                } else {
+                    wave_min_f64_idx(c, ci);
+                }
+                if (lane == 0) {
+                    bslots[0].pc = c;
+                    bslots[0].pi = ci;
+                    bslots[0].tested = ok ? 0u : 1u;
+                }
+            }
+            __syncthreads();
+            pc = bslots[0].pc;
+            pi = bslots[0].pi;
+            if (bslots[0].tested != 0u) status = ST_TEAM_FAIL;
+        }
+        if (status == ST_DONE) {
+            if (pi != NONE) {
+                found = 1;
+                vgoal = j;  // rrt.py:319
+                if (t == 0) {
+                    nodes_g[j] = xg;
+                    vcost[j] = pc;
+                    parent[j] = (int32_t)pi;
+                }
+            } else {
+                if (j < n) status = ST_UNREACHABLE;
+                vgoal = 0;  // rrt.py:330-331
+            }
         }
         STAMP(5);
     }

@@ -176,16 +176,18 @@ struct BSlot {
 constexpr int G2G_NB = 2048;  // cost buckets (2 x 8 KiB of LDS: fill cursors and bucket ends)
 constexpr int G2G_U = 4;      // nodes a wave tests per round
 
-__device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const uint32_t *nodes_g, const double *vcost, int j, uint32_t xg,
-                                              uint32_t *order, RRT_LDS uint32_t *lds16k, BSlot *bslots, int t, int lane, int wave,
-                                              double &pc, uint32_t &pi) {
+// The nodes considered are kfirst + m * kstep, m < cnt (all of them: 0, 1, j; a team gives each member a stripe and takes the
+// minimum of the stripes' answers).
+__device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const uint32_t *nodes_g, const double *vcost, int kfirst, int kstep,
+                                              int cnt, uint32_t xg, uint32_t *order, RRT_LDS uint32_t *lds16k, BSlot *bslots, int t, int lane,
+                                              int wave, double &pc, uint32_t &pi) {
     RRT_LDS uint32_t *cursor = lds16k;          // [G2G_NB]
     RRT_LDS uint32_t *bend = lds16k + G2G_NB;   // [G2G_NB]
     auto cost_of = [&](int k) -> double { return vcost[k] + sqrt_u32(dist2(nodes_g[k], xg)); };  // rrt.py:313-314
     // ---- cost range ----
     double cmin = f64_inf(), cmax = 0.0;
-    for (int k = t; k < j; k += TPB) {
-        const double c = cost_of(k);
+    for (int m = t; m < cnt; m += TPB) {
+        const double c = cost_of(kfirst + m * kstep);
         cmin = c < cmin ? c : cmin;
         cmax = c > cmax ? c : cmax;
     }
@@ -224,7 +226,8 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
     // ---- histogram, exclusive scan, scatter ----
     for (int b = t; b < 2 * G2G_NB; b += TPB) lds16k[b] = 0;
     __syncthreads();
-    for (int k = t; k < j; k += TPB) __hip_atomic_fetch_add(&cursor[bucket_of(cost_of(k))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int m = t; m < cnt; m += TPB)
+        __hip_atomic_fetch_add(&cursor[bucket_of(cost_of(kfirst + m * kstep))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     {
         // thread t owns buckets 2t, 2t+1 (G2G_NB == 2 * TPB)
@@ -247,7 +250,8 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
         bend[2 * t + 1] = ex + c0 + c1;
         __syncthreads();
     }
-    for (int k = t; k < j; k += TPB) {
+    for (int m = t; m < cnt; m += TPB) {
+        const int k = kfirst + m * kstep;
         const uint32_t pos = __hip_atomic_fetch_add(&cursor[bucket_of(cost_of(k))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         order[pos] = (uint32_t)k;
     }
@@ -255,7 +259,7 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
     // ---- test in bucket order ----
     pc = f64_inf();
     pi = NONE;
-    uint32_t limit = (uint32_t)j;
+    uint32_t limit = (uint32_t)cnt;
     int round = 0;
     for (uint32_t pos0 = 0; pos0 < limit; pos0 += NWAVE * G2G_U) {
         double bc = f64_inf();
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         status = ST_DONE;
         double pc;
         uint32_t pi;
-        go2goal_phase(og, H, nodes_g, vcost, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)smem, bslots, t, lane, wave, pc, pi);
+        go2goal_phase(og, H, nodes_g, vcost, 0, 1, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)smem, bslots, t, lane, wave, pc, pi);
         if (pi != NONE) {
             found = 1;
             vgoal = j;  // rrt.py:319
