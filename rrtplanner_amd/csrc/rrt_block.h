@@ -50,8 +50,11 @@ constexpr int CG = 2;   // cells whose records an owner streams concurrently
 // by a wall-clock limit that fails the query (status ST_TEAM_FAIL, the host then continues it with one CU) instead of
 // hanging the device.
 constexpr int TEAM_MAX = 64;
-constexpr int TEAM_BYTES = 24576;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
-constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 2 x 64 */, TEAM_OFF_REC = 512 /* 2 x 6656 */, TEAM_OFF_ARRIVE = 13824 /* 65 x 128 */, TEAM_OFF_RES = 22144 /* 65 x 16 */;
+#ifndef RRT_PIPE_LAG
+#define RRT_PIPE_LAG 2  // blocks a pipelined team's workers run ahead of the commit (RRTStandard / RRTStar; an Informed batch: 1)
+#endif
+constexpr int TEAM_BYTES = 36864;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
+constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 3 x 64 */, TEAM_OFF_REC = 1024 /* 3 x 8192 */, TEAM_OFF_ARRIVE = 25600 /* 65 x 128 */, TEAM_OFF_RES = 33920 /* 65 x 16 */;
 constexpr unsigned long long TEAM_TIMEOUT_TICKS = 50000000ull;  // 0.5 s of the 100 MHz wall clock
 
 typedef unsigned long long u64;
@@ -116,7 +119,7 @@ __device__ __forceinline__ uint32_t key16(uint32_t node_s, uint32_t q_s, uint32_
     return r;
 }
 
-// Owner's publication for one sample (104 bytes = 13 words of 8 bytes).
+// Owner's publication for one sample (128 bytes = 16 words of 8 bytes).
 struct BRec {
     uint32_t d2s, vs;   // snapshot nearest
     uint32_t los_s;     // line of sight vs -> sample: bit 31 free, low bits cells read
@@ -131,10 +134,11 @@ struct BRec {
     u64 nnmask;         // earlier samples of the (super-)block strictly nearer than the snapshot nearest
     u64 rmask;          // earlier samples within r_rewire
     u64 dupmask;        // earlier samples on the same cell
-    u64 pnn, pr, pdup;  // pipelined teams: the same three masks against the samples of the previous super-block
+    u64 pnn[2], pr[2], pdup[2];  // pipelined teams: the same three masks against the samples of the previous super-block [0]
+                                 // and of the one before it [1] (workers two blocks ahead of the commit)
 };
-constexpr int BREC_WORDS = 13;
-static_assert(sizeof(BRec) == 8 * BREC_WORDS, "BRec must be 104 bytes");
+constexpr int BREC_WORDS = 16;
+static_assert(sizeof(BRec) == 8 * BREC_WORDS, "BRec must be 128 bytes");
 union BRecWords {
     BRec r;
     u64 w[BREC_WORDS];
@@ -183,6 +187,11 @@ template <int G, int BSM, bool PIPE, bool INF>
 __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM <= BS && BSM * G <= 64, "team size");
     static_assert(!PIPE || G > 1, "a pipeline needs a team");
+    // How far the workers run ahead of the commit: two blocks (RRTStandard / RRTStar: every record carries masks against the
+    // samples of BOTH blocks in flight), one block when the batch may hold Informed queries (a block in flight can be voided).
+    constexpr int LAG = PIPE ? (INF ? 1 : RRT_PIPE_LAG) : 0;
+    constexpr int NP = LAG > 0 ? LAG : 1;       // previous blocks a record / the commit looks at (array extents)
+    constexpr int NSLOT = PIPE ? LAG + 1 : 1;   // record and state buffers in the hand-off area: by block number modulo NSLOT
     constexpr int SB = BSM * G;  // samples per (super-)block: one lane of the committing wave each; BSM per member
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
     __shared__ __attribute__((aligned(16))) u32x2 nnx[BSM * NWAVE];        // per own sample, per wave: {d2, idx}
@@ -193,14 +202,14 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     __shared__ uint32_t xq_lds[SB];
     __shared__ double newcost[SB];
     struct ParRound {  // pipelined committer: the samples re-resolved side by side, one wave each
-        u64 acc_opt, aprev;
+        u64 acc_opt, aprev[2];
         uint32_t list[NWAVE], acc[NWAVE];
         uint32_t count;
-        int32_t jp0;
+        int32_t jp0[2];
     };
     __shared__ __attribute__((aligned(16))) ParRound par;
-    __shared__ uint32_t xqp_lds[PIPE ? 64 : 1];   // pipelined teams: the samples of the previous super-block ...
-    __shared__ double prevcost[PIPE ? 64 : 1];    // ... and (committer) the exact costs of the nodes it inserted
+    __shared__ uint32_t xqp_lds[PIPE ? NP : 1][PIPE ? 64 : 1];  // pipelined teams: the samples of the previous super-block(s) ...
+    __shared__ double prevcost[PIPE ? NP : 1][PIPE ? 64 : 1];   // ... and (committer) the exact costs of the nodes they inserted
     constexpr int WPS = NWAVE / BSM;  // waves per sample in the owner phase
     __shared__ __attribute__((aligned(16))) GSlot gslot[NWAVE];
     __shared__ __attribute__((aligned(16))) GCtl gctl[BSM];
@@ -227,8 +236,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #pragma unroll
     for (int k = 0; k < BSM; ++k) pre_best[k] = NONE;
     bool team_failed = false;
-    u64 A_prev = 0;  // pipelined committer: the samples of the previous block that were inserted, and the node count before them
-    int jp0 = 0;
+    u64 A_prev[NP];  // pipelined committer: the samples of the previous block(s) that were inserted, and the node count before each
+    int jp0[NP];
+#pragma unroll
+    for (int p2 = 0; p2 < NP; ++p2) {
+        A_prev[p2] = 0;
+        jp0[p2] = 0;
+    }
 
     // ---- per-query views ----
     const int n = D->n, alg = D->alg;
@@ -276,6 +290,19 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
     unsigned long long wcyc_acc = 0, wcyc_los = 0;
+    __shared__ unsigned long long dbg[12];  // pipelined teams: phase cycles of wave 0 of the committer and of worker 1
+    if (t < 12) dbg[t] = 0;
+    unsigned long long dbgt = __builtin_amdgcn_s_memtime();
+#define DBGT(k)                                                  \
+    do {                                                         \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        if (t == 0) dbg[k] += now_ - dbgt;                       \
+        dbgt = now_;                                             \
+    } while (0)
+#else
+#define DBGT(k) \
+    do {        \
+    } while (0)
 #endif
 
     const double xc0 = ((double)(D->xs[0] + D->xg[0])) / 2.0, xc1 = ((double)(D->xs[1] + D->xg[1])) / 2.0;
@@ -647,7 +674,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     // true state.  A worker therefore never ends the loop on its own count: it leaves when a state says the run is over.
     constexpr int32_t ST_FLAG_RESTART = 1, ST_FLAG_STOP = 2;
     const bool pipe_inf = PIPE && informed;
-    bool prev_valid = true;   // worker: the previous block exists (its samples are in xqp_lds)
+    int nprev = 0;            // worker: how many previous blocks exist (their samples are in xqp_lds[0 .. nprev))
     bool void_next = false;   // committer: the last commit ended early or changed the ellipse
     auto publish_state = [&](uint32_t ep, int32_t flags) {  // wave 0 of member 0: state of block `ep`, then its go flag
         if (lane == 0) {
@@ -661,7 +688,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             u.b.cmin_soln = cmin_soln;
             u.b.c_ell = c_ell;
 #pragma unroll
-            for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + (PIPE ? (size_t)(ep & 1u) * 8 : 0) + w, u.w[w], RRT_RLX_AGENT);
+            for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + (size_t)(ep % NSLOT) * 8 + w, u.w[w], RRT_RLX_AGENT);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // wave 0 made every store of the commit
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the flag must not overtake the write-back
@@ -699,8 +726,11 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 if (lane == 0) blk.pad0 = ok ? 0 : 1;
             }
             void_next = false;
-            A_prev = 0;
-            jp0 = j;
+#pragma unroll
+            for (int p2 = 0; p2 < NP; ++p2) {
+                A_prev[p2] = 0;
+                jp0[p2] = j;
+            }
             __syncthreads();
             if (blk.pad0 != 0) {
                 team_failed = true;
@@ -836,7 +866,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.nnear = nnear;
                 r.pad = 0;
                 r.pc = pc;
-                r.pnn = r.pr = r.pdup = 0;
+                r.pnn[0] = r.pnn[1] = r.pr[0] = r.pr[1] = r.pdup[0] = r.pdup[1] = 0;
                 brec[sidx] = r;
             }
         }
@@ -861,7 +891,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             bool free_s = false;
             int cells = 0;
             uint32_t bm_word = 0;
-            u64 nnmask = 0, rmask = 0, dupmask = 0, pnn = 0, pr = 0, pdup = 0;
+            u64 nnmask = 0, rmask = 0, dupmask = 0, pnn[2] = {0, 0}, pr[2] = {0, 0}, pdup[2] = {0, 0};
             const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
             uint32_t own_nlist = 0;
             uint32_t vsxy = Xk;
@@ -901,12 +931,17 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 nnmask = __ballot(lane < sidx && dk < d2s);
                 rmask = __ballot(lane < sidx && star && dk < r2);
                 dupmask = __ballot(lane < sidx && xo == Xk);
-                if (PIPE && epoch >= 2 && prev_valid) {  // ... and every sample of the previous block, which is being committed meanwhile
-                    const uint32_t xop = xqp_lds[lane];
-                    const uint32_t dp = dist2(xop, Xk);
-                    pnn = __ballot(dp < d2s);
-                    pr = __ballot(star && dp < r2);
-                    pdup = __ballot(xop == Xk);
+                if (PIPE) {  // ... and every sample of the blocks in flight, which are being committed meanwhile
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) {
+                        if (p2 < nprev) {
+                            const uint32_t xop = xqp_lds[p2][lane];
+                            const uint32_t dp = dist2(xop, Xk);
+                            pnn[p2] = __ballot(dp < d2s);
+                            pr[p2] = __ballot(star && dp < r2);
+                            pdup[p2] = __ballot(xop == Xk);
+                        }
+                    }
                 }
                 if (star) {
                     Top2 tt;
@@ -1022,9 +1057,12 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.nnear = nnear;
                 r.pad = 0;
                 r.pc = pc;
-                r.pnn = pnn;
-                r.pr = pr;
-                r.pdup = pdup;
+                r.pnn[0] = pnn[0];
+                r.pnn[1] = pnn[1];
+                r.pr[0] = pr[0];
+                r.pr[1] = pr[1];
+                r.pdup[0] = pdup[0];
+                r.pdup[1] = pdup[1];
                 brec[sidx] = r;
             }
         }
@@ -1039,24 +1077,29 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         // ---------------- a pipelined team's workers: hand the records of block s over and, instead of waiting for its commit,
         //                  take the nodes of the commit of block s - 1 and go on with block s + 1 ----------------
         if (PIPE && g > 0) {
+            DBGT(0);
             const bool more = i0 + nb < n;
-            const bool take = epoch >= 2 && (more || pipe_inf);  // there is a commit to take (an Informed worker always looks)
+            const bool take = (int)epoch > LAG && (more || pipe_inf);  // there is a commit to take (an Informed worker always looks)
             if (wave == 0) {
                 if (!void_blk) {
                     const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[wg * BSM];
-                    gu64 *dst = t_rec + (size_t)(epoch & 1u) * 64 * BREC_WORDS + (size_t)wg * BSM * BREC_WORDS;
+                    gu64 *dst = t_rec + (size_t)(epoch % NSLOT) * 64 * BREC_WORDS + (size_t)wg * BSM * BREC_WORDS;
                     for (int w = lane; w < BSM * BREC_WORDS; w += 64) __hip_atomic_store(dst + w, src[w], RRT_RLX_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
                 }
                 if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
                 bool ok = true;
+                DBGT(1);
                 if (take) {
-                    ok = team_wait(t_go, epoch - 1, t_fail);
+                    ok = team_wait(t_go, epoch - LAG, t_fail);
+                    DBGT(2);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
                 }
                 if (lane == 0) blk.pad0 = ok ? 0 : 1;
-                xqp_lds[lane] = xv;  // the next block's "previous" samples (a block that has a successor is full)
+#pragma unroll
+                for (int p2 = NP - 1; p2 > 0; --p2) xqp_lds[p2][lane] = xqp_lds[p2 - 1][lane];
+                xqp_lds[0][lane] = xv;  // the next block's "previous" samples (a block that has a successor is full)
             }
             __syncthreads();
             if (blk.pad0 != 0) {
@@ -1064,11 +1107,11 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 break;
             }
             i = i0 + nb;
-            prev_valid = !void_blk;
+            nprev = void_blk ? 0 : (nprev < NP ? nprev + 1 : NP);
             if (take) {
                 BlkWords u;
 #pragma unroll
-                for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + (size_t)((epoch - 1) & 1u) * 8 + w, RRT_RLX_AGENT);
+                for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + (size_t)((epoch - LAG) % NSLOT) * 8 + w, RRT_RLX_AGENT);
                 if (pipe_inf && ((u.b.pad1 & ST_FLAG_STOP) != 0 || u.b.i >= n)) break;  // the run is over (or waits for the host)
                 const int jn = u.b.j;
                 if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
@@ -1097,14 +1140,15 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         }
                         BlkWords u2;
 #pragma unroll
-                        for (int w = 0; w < 5; ++w) u2.w[w] = __hip_atomic_load(t_state + (size_t)(epoch & 1u) * 8 + w, RRT_RLX_AGENT);
+                        for (int w = 0; w < 5; ++w) u2.w[w] = __hip_atomic_load(t_state + (size_t)(epoch % NSLOT) * 8 + w, RRT_RLX_AGENT);
                         if ((u2.b.pad1 & ST_FLAG_STOP) != 0) break;
                         i = u.b.i;
-                        prev_valid = false;
+                        nprev = 0;
                     }
                 }
             }
             __syncthreads();
+            DBGT(3);
             continue;
         }
 
@@ -1167,16 +1211,18 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 
         // ---------------- C: commit (member 0; wave 0, one lane per sample) ----------------
         // References to nodes the commit itself inserts are kept as sample references until the store pass knows every node
-        // index: 0x80000000 + kk = sample kk of the previous block (pipelined teams), 0x80000040 + kk = sample kk of this block.
+        // index: 0x80000000 + 64 set + kk = sample kk of previous block `set` (pipelined teams: oldest first), set = NP: of this block.
         // They compare like the node indices they stand for (above every snapshot index, previous block first, sample order).
         BRec r;
         r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnear = r.pad = 0;
-        r.nnmask = r.rmask = r.dupmask = r.pnn = r.pr = r.pdup = 0;
+        r.nnmask = r.rmask = r.dupmask = 0;
+        r.pnn[0] = r.pnn[1] = r.pr[0] = r.pr[1] = r.pdup[0] = r.pdup[1] = 0;
         r.Vs = r.cbest = r.pc = 0.0;
         const u64 lbit = 1ull << lane;
         const u64 ltmask = lbit - 1ull;  // lanes below
         bool acc0 = false, goalhit = false, remote_ok = true;
-        u64 harm = 0, pbad = 0, acc_exact = 0, fin = 0, fin_acc = 0;  // fin: samples already re-resolved (by the parallel round)
+        u64 harm = 0, acc_exact = 0, fin = 0, fin_acc = 0;  // fin: samples already re-resolved (by the parallel round)
+        bool pbad = false;  // an inserted sample of a previous block affects this sample
         // harm: the earlier samples within r_rewire that, once inserted at their cost, would be tried as this sample's parent
         // before the snapshot's choice: cost-through-it < cost through the snapshot parent (ties go to the lower index = the
         // snapshot, rrt.py:518-521).  A single-precision bound settles almost every pair; bit k is re-evaluated when sample
@@ -1189,8 +1235,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             return nc + sqrt_u32(d2) < r.cbest;
         };
         // Sample k on its own, re-resolved against snapshot + inserted nodes of this block (accepted: acc_k) and of the previous
-        // one (ap, their count base jp): any wave.  Its record in LDS is replaced by the final one; returns acceptance and cost.
-        auto resolve_sample = [&](int k, u64 acc_k, u64 ap, int jp, bool check_full, bool &acc, double &cbest) {
+        // ones (ap[], their count bases jp[]): any wave.  Its record in LDS is replaced by the final one; returns acceptance and cost.
+        // Block references: 0x80000000 + 64 * set + kk with set 0 = the oldest previous block ... NP = this block.
+        auto resolve_sample = [&](int k, u64 acc_k, const u64 (&ap)[NP], const int (&jp)[NP], bool check_full, bool &acc, double &cbest) {
             const BRec rk = brec[k];
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
             uint32_t vn = rk.vs, d2n = rk.d2s;
@@ -1202,32 +1249,49 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             uint32_t ntests = rk.pstat >> 20, tcells = rk.pstat & 0xfffffu;
             const uint32_t xo = (lane < SB) ? xq_lds[lane] : Xk;  // lane kk: sample kk
             const uint32_t dk = dist2(xo, Xk);
-            // pipelined: lane kk also stands for sample kk of the previous block (inserted ones: ap, exact costs)
-            const uint32_t xop = PIPE ? xqp_lds[lane] : Xk;
-            const uint32_t dkp = dist2(xop, Xk);
-            const int snapj = PIPE ? jp : j0;  // the node count the sample's owner resolved it against
-            const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_k) != 0 || (PIPE && (rk.pdup & ap) != 0);
+            // pipelined: lane kk also stands for sample kk of each previous block (inserted ones: ap[p], exact costs)
+            uint32_t xop[NP], dkp[NP];
+            u64 pnm[NP], pany = 0;
+            bool pdup_hit = false;
+#pragma unroll
+            for (int p2 = 0; p2 < NP; ++p2) {
+                xop[p2] = PIPE ? xqp_lds[p2][lane] : Xk;
+                dkp[p2] = dist2(xop[p2], Xk);
+                pnm[p2] = PIPE ? (rk.pnn[p2] & ap[p2]) : 0ull;
+                pany |= pnm[p2];
+                pdup_hit = pdup_hit || (PIPE && (rk.pdup[p2] & ap[p2]) != 0);
+            }
+            const int snapj = PIPE ? jp[NP - 1] : j0;  // the node count the sample's owner resolved it against
+            const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_k) != 0 || pdup_hit;
             const u64 nm = rk.nnmask & acc_k;
-            const u64 pnm = PIPE ? (rk.pnn & ap) : 0ull;
             bool nn_inblock = false;
-            if (nm | pnm) {  // nearest is an inserted block node: smallest distance, lowest node index on ties
-                uint32_t kd = (nm & lbit) ? dk : NONE, kk = (uint32_t)lane;
-                wave_min_key_idx(kd, kk);
-                uint32_t kdp = (pnm & lbit) ? dkp : NONE, kkp = (uint32_t)lane;
-                wave_min_key_idx(kdp, kkp);
+            if (nm | pany) {  // nearest is an inserted block node: smallest distance, lowest node index on ties (oldest block first)
                 nn_inblock = true;
-                uint32_t axy;
-                if (pnm != 0 && (nm == 0 || kdp <= kd)) {  // a node of the previous block (its indices are the lower ones)
-                    d2n = kdp;
-                    vn = 0x80000000u + kkp;
-                    Vn = prevcost[kkp];
-                    axy = (uint32_t)__builtin_amdgcn_readlane((int)xop, (int)kkp);
-                } else {
-                    d2n = kd;
-                    vn = 0x80000040u + kk;
-                    Vn = newcost[kk];
-                    axy = (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk);
+                uint32_t bestd = NONE, axy = Xk;
+#pragma unroll
+                for (int p2 = NP - 1; p2 >= 0; --p2) {
+                    if (pnm[p2] != 0) {
+                        uint32_t kdp = (pnm[p2] & lbit) ? dkp[p2] : NONE, kkp = (uint32_t)lane;
+                        wave_min_key_idx(kdp, kkp);
+                        if (kdp < bestd) {
+                            bestd = kdp;
+                            vn = 0x80000000u + (uint32_t)(NP - 1 - p2) * 64u + kkp;
+                            Vn = prevcost[p2][kkp];
+                            axy = (uint32_t)__builtin_amdgcn_readlane((int)xop[p2], (int)kkp);
+                        }
+                    }
                 }
+                if (nm != 0) {
+                    uint32_t kd = (nm & lbit) ? dk : NONE, kk = (uint32_t)lane;
+                    wave_min_key_idx(kd, kk);
+                    if (kd < bestd) {
+                        bestd = kd;
+                        vn = 0x80000000u + (uint32_t)NP * 64u + kk;
+                        Vn = newcost[kk];
+                        axy = (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk);
+                    }
+                }
+                d2n = bestd;
                 int cc = 0;
                 nocoll = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:424
                 cells = (uint32_t)cc;
@@ -1250,10 +1314,16 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 }
                 // inserted block nodes within r_rewire, in (cost, index) order, while they beat the snapshot's best
                 u64 rm = rk.rmask & acc_k;
-                u64 rmp = PIPE ? (rk.pr & ap) : 0ull;
-                nnear += (uint32_t)__builtin_popcountll(rm) + (uint32_t)__builtin_popcountll(rmp);
-                while (rm | rmp) {
-                    // every lane's cheaper candidate among "its" sample of this block and of the previous one, then ONE
+                u64 rmp[NP], rmany = rm;
+                nnear += (uint32_t)__builtin_popcountll(rm);
+#pragma unroll
+                for (int p2 = 0; p2 < NP; ++p2) {
+                    rmp[p2] = PIPE ? (rk.pr[p2] & ap[p2]) : 0ull;
+                    rmany |= rmp[p2];
+                    nnear += (uint32_t)__builtin_popcountll(rmp[p2]);
+                }
+                while (rmany) {
+                    // every lane's cheapest candidate among "its" sample of this block and of the previous ones, then ONE
                     // (cost, reference) minimum over the wave
                     double cn = f64_inf();
                     uint32_t ci = NONE;
@@ -1261,21 +1331,28 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         const double c = newcost[lane] + sqrt_u32(dk);
                         if (c < cnear) {
                             cn = c;
-                            ci = 0x80000040u + (uint32_t)lane;
+                            ci = 0x80000000u + (uint32_t)NP * 64u + (uint32_t)lane;
                         }
                     }
-                    if (PIPE && (rmp & lbit)) {
-                        const double c = prevcost[lane] + sqrt_u32(dkp);
-                        if (c < cnear && key_lt(c, 0x80000000u + (uint32_t)lane, cn, ci)) {
-                            cn = c;
-                            ci = 0x80000000u + (uint32_t)lane;
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) {
+                        if (PIPE && (rmp[p2] & lbit)) {
+                            const double c = prevcost[p2][lane] + sqrt_u32(dkp[p2]);
+                            const uint32_t ref = 0x80000000u + (uint32_t)(NP - 1 - p2) * 64u + (uint32_t)lane;
+                            if (c < cnear && key_lt(c, ref, cn, ci)) {
+                                cn = c;
+                                ci = ref;
+                            }
                         }
                     }
                     wave_min_f64_idx(cn, ci);
                     if (ci == NONE || !key_lt(cn, ci, pc, pi)) break;
                     const uint32_t kk = ci & 63u;
-                    const bool from_prev = (ci & 0x40u) == 0;
-                    const uint32_t axy = (uint32_t)__builtin_amdgcn_readlane((int)(from_prev ? xop : xo), (int)kk);
+                    const int set = (int)((ci - 0x80000000u) >> 6);  // 0 .. NP-1: previous blocks, oldest first; NP: this block
+                    uint32_t axy = (uint32_t)__builtin_amdgcn_readlane((int)xo, (int)kk);
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2)
+                        if (set == NP - 1 - p2) axy = (uint32_t)__builtin_amdgcn_readlane((int)xop[p2], (int)kk);
                     int cc = 0;
                     const bool ok = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:519
                     ntests += 1;
@@ -1285,8 +1362,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                         pi = ci;
                         break;
                     }
-                    if (from_prev) rmp &= ~(1ull << kk);
-                    else rm &= ~(1ull << kk);
+                    if (set == NP) rm &= ~(1ull << kk);
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2)
+                        if (set == NP - 1 - p2) rmp[p2] &= ~(1ull << kk);
+                    rmany = rm;
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) rmany |= rmp[p2];
                 }
                 if (pi != NONE) {
                     vbest = pi;
@@ -1311,9 +1393,11 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         //      re-resolved side by side ----
         if (wave == 0) {
             if (G > 1) {  // the other members' records: poll the arrival flags, then loads that bypass the L1
+                DBGT(7);
                 remote_ok = team_wait_all(t_arrive, 1, PIPE ? G : G - 1, epoch, t_fail, lane);
+                DBGT(0);
                 if (remote_ok && (PIPE || lane >= BSM) && lane < nb) {
-                    const gu64 *src = t_rec + (PIPE ? (size_t)(epoch & 1u) * 64 * BREC_WORDS : 0) + (size_t)lane * BREC_WORDS;
+                    const gu64 *src = t_rec + (size_t)(epoch % NSLOT) * 64 * BREC_WORDS + (size_t)lane * BREC_WORDS;
                     BRecWords u;
 #pragma unroll
                     for (int w = 0; w < BREC_WORDS; ++w) u.w[w] = __hip_atomic_load(src + w, RRT_RLX_AGENT);
@@ -1321,6 +1405,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 }
             }
             if (PIPE && lane == 0) par.count = 0;
+            DBGT(8);
             if (!remote_ok) {
                 if (lane == 0) blk.pad0 = 1;
             } else {
@@ -1337,18 +1422,25 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     }
                 }
                 // pipelined: the nodes the previous block inserted are exact; the samples of this block were resolved without them
-                if (PIPE && epoch == 1) jp0 = j0;
+                if (PIPE && epoch == 1) {
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) jp0[p2] = j0;
+                }
                 if (PIPE && lane < nb) {
-                    pbad = (r.pnn | r.pdup) & A_prev;  // inserted samples of the previous block that affect this sample
-                    if (acc0) {
-                        u64 rm = r.pr & A_prev;
-                        while (rm) {
-                            const int kk = __builtin_ctzll(rm);
-                            rm &= rm - 1;
-                            const uint32_t d2 = dist2(xqp_lds[kk], xv);
-                            const double nc = prevcost[kk];
-                            const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
-                            if (low < screen_of(r.cbest) && nc + sqrt_u32(d2) < r.cbest) pbad |= 1ull << kk;
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) {
+                        // inserted samples of a previous block that are nearer than this sample's nearest or sit on its cell
+                        pbad = pbad || ((r.pnn[p2] | r.pdup[p2]) & A_prev[p2]) != 0;
+                        if (acc0) {
+                            u64 rm = r.pr[p2] & A_prev[p2];
+                            while (rm) {
+                                const int kk = __builtin_ctzll(rm);
+                                rm &= rm - 1;
+                                const uint32_t d2 = dist2(xqp_lds[p2][kk], xv);
+                                const double nc = prevcost[p2][kk];
+                                const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
+                                if (low < screen_of(r.cbest) && nc + sqrt_u32(d2) < r.cbest) pbad = true;
+                            }
                         }
                     }
                 }
@@ -1358,7 +1450,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     // interacting with an affected one ("tainted").  Everything else goes through the ordered loop below.
                     const u64 popt = __ballot(acc0);
                     const u64 inter = (r.nnmask | r.dupmask | r.rmask) & ltmask;
-                    const bool slow0 = lane < nb && (((r.nnmask | r.dupmask | harm) & popt & ltmask) != 0 || pbad != 0);
+                    const bool slow0 = lane < nb && (((r.nnmask | r.dupmask | harm) & popt & ltmask) != 0 || pbad);
                     const u64 S0 = __ballot(slow0);
                     u64 taint = S0;
                     for (int it = 0; it < 6; ++it) {
@@ -1376,16 +1468,23 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             if (lane == 0) par.list[cnt] = (uint32_t)k;
                             cnt++;
                         }
+#ifdef RRT_STAMPS
+                        if (t == 0) dbg[6] += cnt;
+#endif
                         if (lane == 0) {
                             par.count = cnt;
                             par.acc_opt = popt;
-                            par.aprev = A_prev;
-                            par.jp0 = jp0;
+#pragma unroll
+                            for (int p2 = 0; p2 < NP; ++p2) {
+                                par.aprev[p2] = A_prev[p2];
+                                par.jp0[p2] = jp0[p2];
+                            }
                         }
                     }
                 }
             }
         }
+        DBGT(1);
         if (PIPE) {  // the parallel round: wave w re-resolves sample par.list[w]
             __syncthreads();
             const uint32_t cnt = par.count;
@@ -1393,11 +1492,19 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 const int k = (int)par.list[wave];
                 bool acc;
                 double cb;
-                resolve_sample(k, par.acc_opt & lowmask64(k), par.aprev, par.jp0, false, acc, cb);
+                u64 ap[NP];
+                int jp[NP];
+#pragma unroll
+                for (int p2 = 0; p2 < NP; ++p2) {
+                    ap[p2] = par.aprev[p2];
+                    jp[p2] = par.jp0[p2];
+                }
+                resolve_sample(k, par.acc_opt & lowmask64(k), ap, jp, false, acc, cb);
                 if (lane == 0) par.acc[wave] = acc ? 1u : 0u;
             }
             __syncthreads();
         }
+        DBGT(2);
         // ---- part B (wave 0): decide in order, store, publish ----
         if (wave == 0 && remote_ok) {
             int cur = 0;
@@ -1431,7 +1538,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 // A sample keeps its snapshot result unless an earlier inserted sample of the block is nearer than its nearest,
                 // sits on its cell, or (accepted samples only) is a harmful candidate parent.
                 const bool slow = lane >= cur && lane < nb && (fin & lbit) == 0 &&
-                                  (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || pbad != 0 || (goalhit && acc0));
+                                  (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || pbad || (goalhit && acc0));
                 const unsigned long long bad = __ballot(slow);
                 const int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
                 acc_exact |= pend & lowmask64(k0) & ~lowmask64(cur);
@@ -1445,6 +1552,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     bool acc;
                     double cbest;
                     resolve_sample(k, acc_exact, A_prev, jp0, true, acc, cbest);
+#ifdef RRT_STAMPS
+                    if (t == 0) dbg[5] += 1;
+#endif
                     if (acc) {
                         if (informed && dist2(Xk, xg) < goal_d2) {  // rrt.py:744-745
                             const bool first = nsoln == 0;
@@ -1464,6 +1574,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     cur = k + 1;
                 }
             }
+            DBGT(3);
             // ---- C2: commit samples [0, cur) in one lane-parallel pass ----
             {
                 if (j0 + __builtin_popcountll(acc_exact) > n) acc_exact &= ~(1ull << (63 - __builtin_clzll(acc_exact)));  // rrt.py:425 `j != n`: only the run's last sample
@@ -1473,8 +1584,12 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 auto node_of = [&](uint32_t v) -> uint32_t {
                     if (v == NONE || (v & 0x80000000u) == 0) return v;
                     const int kk = (int)(v & 63u);
-                    return (v & 0x40u) ? (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & lowmask64(kk))
-                                       : (uint32_t)jp0 + (uint32_t)__builtin_popcountll(A_prev & lowmask64(kk));
+                    const int set = (int)((v - 0x80000000u) >> 6);  // 0 .. NP-1: previous blocks, oldest first; NP: this block
+                    uint32_t node = (uint32_t)j0 + (uint32_t)__builtin_popcountll(acc_exact & lowmask64(kk));
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2)
+                        if (set == NP - 1 - p2) node = (uint32_t)jp0[p2] + (uint32_t)__builtin_popcountll(A_prev[p2] & lowmask64(kk));
+                    return node;
                 };
                 f.vs = node_of(f.vs);
                 f.vbest = node_of(f.vbest);
@@ -1493,9 +1608,11 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 }
                 if (myacc) {
                     if (star) {
+                        uint32_t nprevnear = 0;
+#pragma unroll
+                        for (int p2 = 0; p2 < NP; ++p2) nprevnear += PIPE ? (uint32_t)__builtin_popcountll(f.pr[p2] & A_prev[p2]) : 0u;
                         statred[lane * 5 + 2] += f.pad ? f.nnear
-                                                       : f.nnear + (uint32_t)__builtin_popcountll(f.rmask & acc_exact & ltmask) +
-                                                             (PIPE ? (uint32_t)__builtin_popcountll(f.pr & A_prev) : 0u);
+                                                       : f.nnear + (uint32_t)__builtin_popcountll(f.rmask & acc_exact & ltmask) + nprevnear;
                         statred[lane * 5 + 4] += f.pstat >> 20;
                         statred[lane * 5 + 3] += f.pstat & 0xfffffu;
                     }
@@ -1514,11 +1631,18 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     }
                 }
                 j = j0 + __builtin_popcountll(acc_exact);
-                if (PIPE) {  // this block becomes the previous one
-                    xqp_lds[lane] = xv;
-                    prevcost[lane] = f.cbest;
-                    A_prev = acc_exact;
-                    jp0 = j0;
+                if (PIPE) {  // this block becomes the (newest) previous one
+#pragma unroll
+                    for (int p2 = NP - 1; p2 > 0; --p2) {
+                        xqp_lds[p2][lane] = xqp_lds[p2 - 1][lane];
+                        prevcost[p2][lane] = prevcost[p2 - 1][lane];
+                        A_prev[p2] = A_prev[p2 - 1];
+                        jp0[p2] = jp0[p2 - 1];
+                    }
+                    xqp_lds[0][lane] = xv;
+                    prevcost[0][lane] = f.cbest;
+                    A_prev[0] = acc_exact;
+                    jp0[0] = j0;
                 }
             }
             i = i0 + cur;
@@ -1535,7 +1659,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 blk = b;
             }
             // state first (write-through), then everything the commit stored, then the flag
+            DBGT(9);
             if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0);
+            DBGT(4);
         }
         STAMP(4);
         __syncthreads();
@@ -1574,7 +1700,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         if (blk.pad0 != 0) return;
         BlkWords u;
 #pragma unroll
-        for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + w, RRT_RLX_AGENT);  // FINAL is even: slot 0
+        for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + (size_t)(FINAL % NSLOT) * 8 + w, RRT_RLX_AGENT);
         if ((u.b.pad1 & ST_FLAG_STOP) != 0) return;  // no goal connection this launch (the host has to supply data, or a failure)
         j = u.b.j;
     } else if (G > 1 && status != ST_TEAM_FAIL) {
@@ -1608,6 +1734,11 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, FINAL, RRT_RLX_AGENT);
                 }
+#ifdef RRT_STAMPS
+                if (PIPE && t == 0 && g == 1)
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) D->wcyc[16 + k] = dbg[k];
+#endif
                 return;
             }
             if (wave == 0) {
@@ -1682,10 +1813,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #endif
     }
 #ifdef RRT_STAMPS
-    if (lane == 0) {
+    if (lane == 0 && !PIPE) {
         D->wcyc[wave] = wcyc_acc;
         D->wcyc[16 + wave] = wcyc_los;
     }
+    if (PIPE && t == 0 && g <= 1)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) D->wcyc[16 * g + k] = dbg[k];
 #endif
 }
 

@@ -42,6 +42,10 @@ print(f"kernel {ms:.2f} ms, n={a.n}, nodes={r.c.j}, iters/s={a.n/ms*1e3:.0f}, st
 w = cyc[6:]; cyc = cyc[:6]
 print("per-wave owner-phase cyc/iter:", [round(x / a.n) for x in w[:16]])
 print("per-wave near-set part cyc/iter:", [round(x / a.n) for x in w[16:]])
+if os.environ.get("RRT_STAMPS_PIPE"):
+    nblk = (a.n + 63) // 64
+    print("committer cyc/block [wait, partA, par round, ordered, publish, n ordered, n par, loop top, record loads, store pass]:", [round(x / nblk, 1) for x in w[:10]])
+    print("worker 1  cyc/block [resolve, hand over, go wait, take]:", [round(x / nblk, 1) for x in w[16:20]])
 if os.environ.get("RRT_STAMPS_RAW"):
     print("raw wcyc[0:16]:", list(w[:16]))
     print("raw wcyc[16:]:", list(w[16:]))
