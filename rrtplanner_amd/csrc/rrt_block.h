@@ -183,45 +183,83 @@ union BlkWords {
 // record then also carries the three interaction masks against the samples of block s, and the commit of block s + 1 treats
 // the nodes block s inserted like inserted samples of its own block (their acceptance and costs are exact by then).
 // INF: the batch may hold Informed queries (alg 2); without it everything the ellipse needs is compiled out.
+struct ParRound {  // pipelined committer: the samples re-resolved side by side, one wave each
+    u64 acc_opt, aprev[2];
+    uint32_t list[NWAVE], acc[NWAVE];
+    uint32_t count;
+    int32_t jp0[2];
+};
+
+// How far the workers run ahead of the commit: two blocks (RRTStandard / RRTStar: every record carries masks against the
+// samples of BOTH blocks in flight), one block when the batch may hold Informed queries (a block in flight can be voided).
+template <bool PIPE, bool INF>
+struct PipeShape {
+    static constexpr int LAG = PIPE ? (INF ? 1 : RRT_PIPE_LAG) : 0;
+    static constexpr int NP = LAG > 0 ? LAG : 1;      // previous blocks a record / the commit looks at (array extents)
+    static constexpr int NSLOT = PIPE ? LAG + 1 : 1;  // record and state buffers in the hand-off area: by block number modulo NSLOT
+};
+
+// The static LDS of the block kernel (one object per workgroup, whatever its role).
 template <int G, int BSM, bool PIPE, bool INF>
-__global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
+struct BlockLds {
+    static constexpr int SB = BSM * G, NP = PipeShape<PIPE, INF>::NP;
+    alignas(16) u32x2 nnx[BSM * NWAVE];     // per own sample, per wave: {d2, idx}
+    alignas(16) BRec brec[PIPE ? 2 : 1][SB];  // (a pipelined committer: this block's records and the next one's)
+    uint32_t xq_next[PIPE ? 64 : 1];        // pipelined committer: the next block's samples and whether its records are in
+    uint32_t pre_state;
+    alignas(16) BSlot bslots[2 * NWAVE];
+    alignas(16) BlkState blk;
+    alignas(16) unsigned long long statred[SB * 5];
+    uint32_t xq_lds[SB];
+    double newcost[SB];
+    alignas(16) ParRound par;
+    uint32_t xqp_lds[PIPE ? NP : 1][PIPE ? 64 : 1];  // pipelined teams: the samples of the previous super-block(s) ...
+    double prevcost[PIPE ? NP : 1][PIPE ? 64 : 1];   // ... and (committer) the exact costs of the nodes they inserted
+    alignas(16) GSlot gslot[NWAVE];
+    alignas(16) GCtl gctl[BSM];
+#ifdef RRT_STAMPS
+    unsigned long long dbg[16];  // pipelined teams: phase cycles of wave 0 of the committer and of worker 1
+#endif
+};
+
+// What a workgroup does: everything (teams without a pipeline), or one of the two halves of a pipelined team.  The body is
+// instantiated per role so that neither half carries the other's state through its loop.
+constexpr int ROLE_ALL = 0, ROLE_COMMIT = 1, ROLE_WORK = 2;
+
+template <int G, int BSM, bool PIPE, bool INF, int ROLE>
+__device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PIPE, INF> &L) {
     static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM <= BS && BSM * G <= 64, "team size");
     static_assert(!PIPE || G > 1, "a pipeline needs a team");
-    // How far the workers run ahead of the commit: two blocks (RRTStandard / RRTStar: every record carries masks against the
-    // samples of BOTH blocks in flight), one block when the batch may hold Informed queries (a block in flight can be voided).
-    constexpr int LAG = PIPE ? (INF ? 1 : RRT_PIPE_LAG) : 0;
-    constexpr int NP = LAG > 0 ? LAG : 1;       // previous blocks a record / the commit looks at (array extents)
-    constexpr int NSLOT = PIPE ? LAG + 1 : 1;   // record and state buffers in the hand-off area: by block number modulo NSLOT
+    static_assert(PIPE == (ROLE != ROLE_ALL), "roles are the halves of a pipelined team");
+    constexpr int LAG = PipeShape<PIPE, INF>::LAG, NP = PipeShape<PIPE, INF>::NP, NSLOT = PipeShape<PIPE, INF>::NSLOT;
     constexpr int SB = BSM * G;  // samples per (super-)block: one lane of the committing wave each; BSM per member
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
-    __shared__ __attribute__((aligned(16))) u32x2 nnx[BSM * NWAVE];        // per own sample, per wave: {d2, idx}
-    __shared__ __attribute__((aligned(16))) BRec brec[SB];
-    __shared__ __attribute__((aligned(16))) BSlot bslots[2 * NWAVE];
-    __shared__ __attribute__((aligned(16))) BlkState blk;
-    __shared__ __attribute__((aligned(16))) unsigned long long statred[SB * 5];
-    __shared__ uint32_t xq_lds[SB];
-    __shared__ double newcost[SB];
-    struct ParRound {  // pipelined committer: the samples re-resolved side by side, one wave each
-        u64 acc_opt, aprev[2];
-        uint32_t list[NWAVE], acc[NWAVE];
-        uint32_t count;
-        int32_t jp0[2];
-    };
-    __shared__ __attribute__((aligned(16))) ParRound par;
-    __shared__ uint32_t xqp_lds[PIPE ? NP : 1][PIPE ? 64 : 1];  // pipelined teams: the samples of the previous super-block(s) ...
-    __shared__ double prevcost[PIPE ? NP : 1][PIPE ? 64 : 1];   // ... and (committer) the exact costs of the nodes they inserted
+    auto &nnx = L.nnx;
+    auto &brec = L.brec;
+    auto &xq_next = L.xq_next;
+    auto &pre_state = L.pre_state;
+    auto &bslots = L.bslots;
+    auto &blk = L.blk;
+    auto &statred = L.statred;
+    auto &xq_lds = L.xq_lds;
+    auto &newcost = L.newcost;
+    auto &par = L.par;
+    auto &xqp_lds = L.xqp_lds;
+    auto &prevcost = L.prevcost;
+    auto &gslot = L.gslot;
+    auto &gctl = L.gctl;
     constexpr int WPS = NWAVE / BSM;  // waves per sample in the owner phase
-    __shared__ __attribute__((aligned(16))) GSlot gslot[NWAVE];
-    __shared__ __attribute__((aligned(16))) GCtl gctl[BSM];
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
-    int q = (int)blockIdx.x, g = 0;  // query, team member
+    int q = (int)blockIdx.x, g_ = 0;  // query, team member
     if (G > 1) {
         q = (int)blockIdx.x % bv.team_qpad;  // members of one team are 8k blocks apart: dealt to the same XCD (speed only)
-        g = (int)blockIdx.x / bv.team_qpad;
+        g_ = (int)blockIdx.x / bv.team_qpad;
         if (q >= bv.Q) return;
-        if (bv.team_fault && g == 1) return;
+        if (bv.team_fault && g_ == 1) return;
     }
-    const bool worker = !PIPE || g > 0;  // scans and resolves samples (a pipelined team's member 0 only commits)
+    const int g = ROLE == ROLE_COMMIT ? 0 : g_;
+    if (ROLE == ROLE_WORK) __builtin_assume(g > 0);
+    const bool worker = !PIPE || ROLE == ROLE_WORK;  // scans and resolves samples (a pipelined team's member 0 only commits)
     const int wg = PIPE ? g - 1 : g;     // which BSM samples of a super-block this workgroup owns
     QDesc *D = bv.desc + q;
     if (D->status != ST_RUNNING) return;
@@ -290,8 +328,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
     unsigned long long wcyc_acc = 0, wcyc_los = 0;
-    __shared__ unsigned long long dbg[12];  // pipelined teams: phase cycles of wave 0 of the committer and of worker 1
-    if (t < 12) dbg[t] = 0;
+    auto &dbg = L.dbg;
+    if (t < 16) dbg[t] = 0;
     unsigned long long dbgt = __builtin_amdgcn_s_memtime();
 #define DBGT(k)                                                  \
     do {                                                         \
@@ -676,6 +714,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     const bool pipe_inf = PIPE && informed;
     int nprev = 0;            // worker: how many previous blocks exist (their samples are in xqp_lds[0 .. nprev))
     bool void_next = false;   // committer: the last commit ended early or changed the ellipse
+    bool prefetched = false;  // committer: wave 1 fetched this block's samples and records during the last commit
+    int bsel = 0;             // committer: which half of brec holds this block's records
     auto publish_state = [&](uint32_t ep, int32_t flags) {  // wave 0 of member 0: state of block `ep`, then its go flag
         if (lane == 0) {
             BlkWords u;
@@ -738,6 +778,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             }
             continue;
         }
+        if (ROLE == ROLE_COMMIT) DBGT(0);
         uint32_t xv = 0;  // lane s < nb: sample s
         if (lane < nb) {
             if (ell) {
@@ -754,7 +795,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 vy = (vy > 0.0) ? vy : 0.0;
                 xv = pack_xy((int)vx, (int)vy);
             } else {
-                xv = (G > 1 && !PIPE && pre_i == i0) ? pre_xv : samples[i0 + lane];
+                xv = (G > 1 && !PIPE && pre_i == i0) ? pre_xv : (PIPE && prefetched) ? xq_next[lane] : samples[i0 + lane];
             }
         }
         if (!worker && t < SB) xq_lds[t] = xv;  // a pipelined team's committer: nothing to resolve
@@ -867,7 +908,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.pad = 0;
                 r.pc = pc;
                 r.pnn[0] = r.pnn[1] = r.pr[0] = r.pr[1] = r.pdup[0] = r.pdup[1] = 0;
-                brec[sidx] = r;
+                brec[0][sidx] = r;
             }
         }
         } else {
@@ -1063,7 +1104,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 r.pr[1] = pr[1];
                 r.pdup[0] = pdup[0];
                 r.pdup[1] = pdup[1];
-                brec[sidx] = r;
+                brec[0][sidx] = r;
             }
         }
 #ifdef RRT_STAMPS
@@ -1082,7 +1123,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             const bool take = (int)epoch > LAG && (more || pipe_inf);  // there is a commit to take (an Informed worker always looks)
             if (wave == 0) {
                 if (!void_blk) {
-                    const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[wg * BSM];
+                    const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[0][wg * BSM];
                     gu64 *dst = t_rec + (size_t)(epoch % NSLOT) * 64 * BREC_WORDS + (size_t)wg * BSM * BREC_WORDS;
                     for (int w = lane; w < BSM * BREC_WORDS; w += 64) __hip_atomic_store(dst + w, src[w], RRT_RLX_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
@@ -1157,7 +1198,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             if (wave == 0) {
                 // this member's 16 records, LDS -> HBM: whole 128-byte lines per wave instruction, write-through (8-byte
                 // stores of single lanes are partial-line fabric writes and delay everything queued behind them)
-                const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[g * BSM];
+                const RRT_LDS u64 *src = (const RRT_LDS u64 *)&brec[0][g * BSM];
                 for (int w = lane; w < BSM * BREC_WORDS; w += 64) __hip_atomic_store(t_rec + (size_t)g * BSM * BREC_WORDS + w, src[w], RRT_RLX_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
                 if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
@@ -1221,7 +1262,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         const u64 lbit = 1ull << lane;
         const u64 ltmask = lbit - 1ull;  // lanes below
         bool acc0 = false, goalhit = false, remote_ok = true;
-        u64 harm = 0, acc_exact = 0, fin = 0, fin_acc = 0;  // fin: samples already re-resolved (by the parallel round)
+        u64 harm = 0, acc_exact = 0, fin = 0, fin_acc = 0;  // fin: samples already re-resolved (by the parallel rounds)
+        u64 popt = 0, inter = 0, known = 0, aknown = 0;  // parallel rounds: samples whose final result is known, the accepted ones
+        bool rounds_on = false;
         bool pbad = false;  // an inserted sample of a previous block affects this sample
         // harm: the earlier samples within r_rewire that, once inserted at their cost, would be tried as this sample's parent
         // before the snapshot's choice: cost-through-it < cost through the snapshot parent (ties go to the lower index = the
@@ -1238,7 +1281,19 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         // ones (ap[], their count bases jp[]): any wave.  Its record in LDS is replaced by the final one; returns acceptance and cost.
         // Block references: 0x80000000 + 64 * set + kk with set 0 = the oldest previous block ... NP = this block.
         auto resolve_sample = [&](int k, u64 acc_k, const u64 (&ap)[NP], const int (&jp)[NP], bool check_full, bool &acc, double &cbest) {
-            const BRec rk = brec[k];
+#ifdef RRT_STAMPS
+            const unsigned long long rs0 = __builtin_amdgcn_s_memtime();
+            bool rs_redo = false;
+#endif
+            BRecWords rku;  // the same record in every lane: kept in scalar registers
+            rku.r = brec[bsel][k];
+#pragma unroll
+            for (int w = 0; w < BREC_WORDS; ++w) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rku.w[w]);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rku.w[w] >> 32));
+                rku.w[w] = ((u64)hi << 32) | lo;
+            }
+            const BRec &rk = rku.r;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
             uint32_t vn = rk.vs, d2n = rk.d2s;
             double Vn = rk.Vs;
@@ -1306,6 +1361,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     if (cnear > cnear_s) {  // entries between the two bounds were never priced: redo the snapshot part
                         ntests = 0;
                         tcells = 0;
+#ifdef RRT_STAMPS
+                        rs_redo = true;
+#endif
                         snapshot_parent(Xk, snapj, true, cnear, pc, pi, nnear, ntests, tcells);
                     } else if (pi != NONE && !(pc < cnear)) {
                         pc = f64_inf();
@@ -1376,7 +1434,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 }
             }
             if (lane == 0) {  // the final record of this sample (pad = 1: nnear already counts the block's nodes)
-                BRec f = rk;
+                BRec &f = brec[bsel][k];
                 f.vs = vn;
                 f.los_s = cells;
                 f.cbest = cbest;
@@ -1384,9 +1442,14 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 f.pstat = (ntests << 20) | (tcells & 0xfffffu);
                 f.nnear = nnear;
                 f.pad = 1;
-                brec[k] = f;
                 newcost[k] = cbest;
             }
+#ifdef RRT_STAMPS
+            if (t == 0) {
+                dbg[rs_redo ? 10 : 12] += __builtin_amdgcn_s_memtime() - rs0;
+                dbg[rs_redo ? 11 : 5] += 1;
+            }
+#endif
         };
 
         // ---- part A (wave 0): the records, the optimistic picture, and for a pipelined committer the samples that can be
@@ -1394,22 +1457,24 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         if (wave == 0) {
             if (G > 1) {  // the other members' records: poll the arrival flags, then loads that bypass the L1
                 DBGT(7);
-                remote_ok = team_wait_all(t_arrive, 1, PIPE ? G : G - 1, epoch, t_fail, lane);
-                DBGT(0);
-                if (remote_ok && (PIPE || lane >= BSM) && lane < nb) {
-                    const gu64 *src = t_rec + (size_t)(epoch % NSLOT) * 64 * BREC_WORDS + (size_t)lane * BREC_WORDS;
-                    BRecWords u;
+                if (PIPE && prefetched) {  // wave 1 fetched them during the last commit
+                    remote_ok = pre_state == 1u;
+                } else {
+                    remote_ok = team_wait_all(t_arrive, 1, PIPE ? G : G - 1, epoch, t_fail, lane);
+                    if (remote_ok && (PIPE || lane >= BSM) && lane < nb) {
+                        const gu64 *src = t_rec + (size_t)(epoch % NSLOT) * 64 * BREC_WORDS + (size_t)lane * BREC_WORDS;
+                        BRecWords u;
 #pragma unroll
-                    for (int w = 0; w < BREC_WORDS; ++w) u.w[w] = __hip_atomic_load(src + w, RRT_RLX_AGENT);
-                    brec[lane] = u.r;
+                        for (int w = 0; w < BREC_WORDS; ++w) u.w[w] = __hip_atomic_load(src + w, RRT_RLX_AGENT);
+                        brec[bsel][lane] = u.r;
+                    }
                 }
             }
-            if (PIPE && lane == 0) par.count = 0;
             DBGT(8);
             if (!remote_ok) {
                 if (lane == 0) blk.pad0 = 1;
             } else {
-                if (lane < nb) r = brec[lane];  // lane s: sample s
+                if (lane < nb) r = brec[bsel][lane];  // lane s: sample s
                 acc0 = lane < nb && (r.los_s >> 31) != 0 && (r.flags & 1u) == 0;  // accepted if nothing in the block interferes
                 goalhit = informed && lane < nb && dist2(xv, xg) < goal_d2;
                 if (lane < nb) newcost[lane] = r.cbest;  // optimistic (snapshot-resolved) cost; exact once the sample has committed
@@ -1446,34 +1511,79 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 }
                 if (PIPE) {
                     // Which affected samples can be re-resolved at once, each by a wave of its own?  Those whose earlier interacting
-                    // samples all keep their snapshot result whatever happens: not affected themselves and (transitively) not
-                    // interacting with an affected one ("tainted").  Everything else goes through the ordered loop below.
-                    const u64 popt = __ballot(acc0);
-                    const u64 inter = (r.nnmask | r.dupmask | r.rmask) & ltmask;
+                    // samples are all known: at first the ones that keep their snapshot result whatever happens -- not affected
+                    // themselves and (transitively) not interacting with an affected one ("tainted"); after a round also the
+                    // samples it settled and the ones that turn out to keep their snapshot result given those.
+                    popt = __ballot(acc0);
+                    inter = (r.nnmask | r.dupmask | r.rmask) & ltmask;
                     const bool slow0 = lane < nb && (((r.nnmask | r.dupmask | harm) & popt & ltmask) != 0 || pbad);
-                    const u64 S0 = __ballot(slow0);
-                    u64 taint = S0;
+                    u64 taint = __ballot(slow0);
                     for (int it = 0; it < 6; ++it) {
                         const u64 t2 = taint | __ballot(lane < nb && (inter & taint) != 0);
                         if (t2 == taint) break;
                         taint = t2;
-                        if (it == 5) taint = ~0ull;  // no fixed point yet: give up on the parallel round
+                        if (it == 5) taint = ~0ull;  // no fixed point yet: nothing is known beforehand
                     }
-                    u64 L0 = __ballot(slow0 && !goalhit && (inter & taint) == 0);  // (a goal hit ends or cuts the block: ordered loop)
-                    if (L0 != 0 && j0 + __builtin_popcountll(popt) < n) {  // (not in the run's last block: `j != n` needs exact counts)
-                        uint32_t cnt = 0;
+                    known = ~taint;
+                    aknown = popt & ~taint;
+                    rounds_on = j0 + __builtin_popcountll(popt) < n;  // (not in the run's last block: `j != n` needs exact counts)
+                }
+            }
+        }
+        DBGT(1);
+        if (PIPE) {  // parallel rounds: wave w re-resolves sample par.list[w]; a round's results make further samples known
+            u64 lastmask = 0;
+            for (;;) {
+                if (wave == 0) {
+                    uint32_t cnt = 0;
+                    if (remote_ok && rounds_on) {
+                        if (lastmask != 0) {  // the samples the last round settled: final, whatever the ordered loop finds
+                            u64 newacc = 0, lm = lastmask;
+                            for (uint32_t w = 0; lm != 0; ++w) {
+                                const int k = __builtin_ctzll(lm);
+                                lm &= lm - 1;
+                                if (par.acc[w] != 0u) newacc |= 1ull << k;
+                            }
+                            fin |= lastmask;
+                            fin_acc |= newacc;
+                            known |= lastmask;
+                            aknown |= newacc;
+                            // their costs are exact now: the later samples they are a candidate parent of look again
+                            u64 rm = r.rmask & newacc;
+                            if (lane < nb && acc0) {
+                                while (rm) {
+                                    const int kk = __builtin_ctzll(rm);
+                                    rm &= rm - 1;
+                                    harm = (harm & ~(1ull << kk)) | (harmful(kk) ? (1ull << kk) : 0ull);
+                                }
+                            }
+                        }
+                        u64 L0 = 0;
+                        for (;;) {  // samples whose earlier interacting samples are all known: unaffected -> known; affected -> this round
+                            const bool ready = lane < nb && (known & lbit) == 0 && (inter & ~known) == 0;
+                            const bool dirty = ((r.nnmask | r.dupmask | harm) & aknown & ltmask) != 0 || pbad || (goalhit && acc0);
+                            const u64 cb = __ballot(ready && !dirty);
+                            if (cb == 0) {
+                                L0 = __ballot(ready && dirty && !goalhit);  // (a goal hit ends or cuts the block: ordered loop)
+                                break;
+                            }
+                            known |= cb;
+                            aknown |= cb & popt;
+                        }
+                        lastmask = 0;
                         while (L0 != 0 && cnt < (uint32_t)NWAVE) {
                             const int k = __builtin_ctzll(L0);
                             L0 &= L0 - 1;
+                            lastmask |= 1ull << k;
                             if (lane == 0) par.list[cnt] = (uint32_t)k;
                             cnt++;
                         }
 #ifdef RRT_STAMPS
                         if (t == 0) dbg[6] += cnt;
+                        if (t == 0 && cnt != 0) dbg[13] += 1;
 #endif
-                        if (lane == 0) {
-                            par.count = cnt;
-                            par.acc_opt = popt;
+                        if (lane == 0 && cnt != 0) {
+                            par.acc_opt = aknown;
 #pragma unroll
                             for (int p2 = 0; p2 < NP; ++p2) {
                                 par.aprev[p2] = A_prev[p2];
@@ -1481,52 +1591,56 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                             }
                         }
                     }
+                    if (lane == 0) par.count = cnt;
                 }
-            }
-        }
-        DBGT(1);
-        if (PIPE) {  // the parallel round: wave w re-resolves sample par.list[w]
-            __syncthreads();
-            const uint32_t cnt = par.count;
-            if ((uint32_t)wave < cnt) {
-                const int k = (int)par.list[wave];
-                bool acc;
-                double cb;
-                u64 ap[NP];
-                int jp[NP];
+                __syncthreads();
+                const uint32_t cnt = par.count;
+                if (cnt == 0) break;
+                if ((uint32_t)wave < cnt) {
+                    const int k = (int)par.list[wave];
+                    bool acc;
+                    double cb;
+                    u64 ap[NP];
+                    int jp[NP];
 #pragma unroll
-                for (int p2 = 0; p2 < NP; ++p2) {
-                    ap[p2] = par.aprev[p2];
-                    jp[p2] = par.jp0[p2];
+                    for (int p2 = 0; p2 < NP; ++p2) {
+                        ap[p2] = par.aprev[p2];
+                        jp[p2] = par.jp0[p2];
+                    }
+                    resolve_sample(k, par.acc_opt & lowmask64(k), ap, jp, false, acc, cb);
+                    if (lane == 0) par.acc[wave] = acc ? 1u : 0u;
                 }
-                resolve_sample(k, par.acc_opt & lowmask64(k), ap, jp, false, acc, cb);
-                if (lane == 0) par.acc[wave] = acc ? 1u : 0u;
+                __syncthreads();
             }
-            __syncthreads();
         }
         DBGT(2);
+        // A pipelined committer's wave 1 meanwhile fetches the next block: its samples, and (workers that run ahead have
+        // handed them over already) its records.  Only an Informed block can end early, so the next block is known.
+        const bool pre_next = PIPE && !informed && i0 + nb < n;
+        if (PIPE && wave == 1 && pre_next) {
+#ifdef RRT_STAMPS
+            const unsigned long long pf0 = __builtin_amdgcn_s_memtime();
+#endif
+            const int in = i0 + nb;
+            const int nbn = (n - in) < SB ? (n - in) : SB;
+            if (lane < nbn) xq_next[lane] = samples[in + lane];
+            const bool ok = team_wait_all(t_arrive, 1, G, epoch + 1, t_fail, lane);
+            if (ok && lane < nbn) {
+                const gu64 *src = t_rec + (size_t)((epoch + 1) % NSLOT) * 64 * BREC_WORDS + (size_t)lane * BREC_WORDS;
+                BRecWords u;
+#pragma unroll
+                for (int w = 0; w < BREC_WORDS; ++w) u.w[w] = __hip_atomic_load(src + w, RRT_RLX_AGENT);
+                brec[bsel ^ 1][lane] = u.r;
+            }
+            if (lane == 0) pre_state = ok ? 1u : 2u;
+#ifdef RRT_STAMPS
+            if (lane == 0) dbg[14] += __builtin_amdgcn_s_memtime() - pf0;
+#endif
+        }
         // ---- part B (wave 0): decide in order, store, publish ----
         if (wave == 0 && remote_ok) {
             int cur = 0;
             bool cut = false;
-            if (PIPE) {
-                const uint32_t cnt = par.count;
-                for (uint32_t w = 0; w < cnt; ++w) {  // the samples the parallel round settled: final, whatever the loop finds
-                    const int k = (int)par.list[w];
-                    fin |= 1ull << k;
-                    if (par.acc[w] != 0u) fin_acc |= 1ull << k;
-                }
-                if (fin != 0) {  // their costs are exact now: the later samples they are a candidate parent of look again
-                    u64 rm = r.rmask & fin & fin_acc;
-                    if (lane < nb && acc0) {
-                        while (rm) {
-                            const int kk = __builtin_ctzll(rm);
-                            rm &= rm - 1;
-                            harm = (harm & ~(1ull << kk)) | (harmful(kk) ? (1ull << kk) : 0ull);
-                        }
-                    }
-                }
-            }
             // ---- C1: decide.  Runs of samples that keep their snapshot result are only marked; a sample that can be affected is
             //      re-resolved on its own and its record in LDS replaced by the final one.  Nothing is stored to HBM yet: the
             //      decisions only read the snapshot and the block's samples. ----
@@ -1552,9 +1666,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                     bool acc;
                     double cbest;
                     resolve_sample(k, acc_exact, A_prev, jp0, true, acc, cbest);
-#ifdef RRT_STAMPS
-                    if (t == 0) dbg[5] += 1;
-#endif
+
                     if (acc) {
                         if (informed && dist2(Xk, xg) < goal_d2) {  // rrt.py:744-745
                             const bool first = nsoln == 0;
@@ -1579,7 +1691,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
             {
                 if (j0 + __builtin_popcountll(acc_exact) > n) acc_exact &= ~(1ull << (63 - __builtin_clzll(acc_exact)));  // rrt.py:425 `j != n`: only the run's last sample
                 const bool inr = lane < cur;
-                BRec f = inr ? brec[lane] : r;
+                const BRec f0 = brec[bsel][lane];  // (lanes at and above `cur`: read, never used)
+                BRec f = f0;
                 // sample references -> node indices, now that every acceptance is known
                 auto node_of = [&](uint32_t v) -> uint32_t {
                     if (v == NONE || (v & 0x80000000u) == 0) return v;
@@ -1665,6 +1778,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         }
         STAMP(4);
         __syncthreads();
+        DBGT(15);
         {
             const BlkState b = blk;
             if (G > 1 && b.pad0 != 0) {
@@ -1672,6 +1786,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
                 break;
             }
             void_next = PIPE && (b.pad1 & ST_FLAG_RESTART) != 0;
+            prefetched = pre_next;
+            if (PIPE && pre_next) bsel ^= 1;
             i = b.i;
             j = b.j;
             nsoln = b.nsoln;
@@ -1737,7 +1853,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
 #ifdef RRT_STAMPS
                 if (PIPE && t == 0 && g == 1)
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) D->wcyc[16 + k] = dbg[k];
+                    for (int k = 0; k < 16; ++k) D->wcyc[16 + k] = dbg[k];
 #endif
                 return;
             }
@@ -1819,8 +1935,25 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     }
     if (PIPE && t == 0 && g <= 1)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) D->wcyc[16 * g + k] = dbg[k];
+        for (int k = 0; k < 16; ++k) D->wcyc[16 * g + k] = dbg[k];
 #endif
+}
+
+template <int G, int BSM, bool PIPE, bool INF>
+__global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
+    __shared__ BlockLds<G, BSM, PIPE, INF> L;
+    if constexpr (PIPE) {
+#if defined(RRT_ONLY_ROLE) && RRT_ONLY_ROLE == 1  // (resource analysis of one role; never run)
+        rrt_block_body<G, BSM, PIPE, INF, ROLE_COMMIT>(bv, L);
+#elif defined(RRT_ONLY_ROLE) && RRT_ONLY_ROLE == 2
+        rrt_block_body<G, BSM, PIPE, INF, ROLE_WORK>(bv, L);
+#else
+        if ((int)blockIdx.x < bv.team_qpad) rrt_block_body<G, BSM, PIPE, INF, ROLE_COMMIT>(bv, L);
+        else rrt_block_body<G, BSM, PIPE, INF, ROLE_WORK>(bv, L);
+#endif
+    } else {
+        rrt_block_body<G, BSM, PIPE, INF, ROLE_ALL>(bv, L);
+    }
 }
 
 }  // namespace rrtdev
