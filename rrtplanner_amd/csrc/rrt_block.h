@@ -64,6 +64,13 @@ typedef __attribute__((address_space(1))) u64 gu64;
 
 __device__ __forceinline__ u64 lowmask64(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
 
+// A value every lane of the wave holds alike (read from LDS or memory): moved to scalar registers, so that it does not
+// take a vector register per lane for as long as it lives.
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int unis32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
+__device__ __forceinline__ double unif64(double v) { return __longlong_as_double((long long)uni64((u64)__double_as_longlong(v))); }
+
 // One wave polls the arrival flags of `count` members starting with member `first` (lane l: member first + l, flags 128 bytes
 // apart) until all have reached `target`.
 __device__ __forceinline__ bool team_wait_all(gu32 *flags, int first, int count, uint32_t target, gu32 *fail, int lane) {
@@ -1458,7 +1465,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (G > 1) {  // the other members' records: poll the arrival flags, then loads that bypass the L1
                 DBGT(7);
                 if (PIPE && prefetched) {  // wave 1 fetched them during the last commit
-                    remote_ok = pre_state == 1u;
+                    remote_ok = uni32(pre_state) == 1u;
                 } else {
                     remote_ok = team_wait_all(t_arrive, 1, PIPE ? G : G - 1, epoch, t_fail, lane);
                     if (remote_ok && (PIPE || lane >= BSM) && lane < nb) {
@@ -1470,7 +1477,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     }
                 }
             }
-            DBGT(8);
+            DBGT(7);
             if (!remote_ok) {
                 if (lane == 0) blk.pad0 = 1;
             } else {
@@ -1534,20 +1541,24 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         if (PIPE) {  // parallel rounds: wave w re-resolves sample par.list[w]; a round's results make further samples known
             u64 lastmask = 0;
             for (;;) {
+                DBGT(2);
                 if (wave == 0) {
                     uint32_t cnt = 0;
-                    if (remote_ok && rounds_on) {
-                        if (lastmask != 0) {  // the samples the last round settled: final, whatever the ordered loop finds
-                            u64 newacc = 0, lm = lastmask;
-                            for (uint32_t w = 0; lm != 0; ++w) {
-                                const int k = __builtin_ctzll(lm);
-                                lm &= lm - 1;
-                                if (par.acc[w] != 0u) newacc |= 1ull << k;
-                            }
-                            fin |= lastmask;
-                            fin_acc |= newacc;
-                            known |= lastmask;
-                            aknown |= newacc;
+                    u64 newacc = 0;
+                    if (lastmask != 0) {  // the samples the last round settled: final, whatever the ordered loop finds
+                        u64 lm = lastmask;
+                        for (uint32_t w = 0; lm != 0; ++w) {
+                            const int k = __builtin_ctzll(lm);
+                            lm &= lm - 1;
+                            if (uni32(par.acc[w]) != 0u) newacc |= 1ull << k;
+                        }
+                        fin |= lastmask;
+                        fin_acc |= newacc;
+                        known |= lastmask;
+                        aknown |= newacc;
+                    }
+                    if (remote_ok && rounds_on && (~known & lowmask64(nb)) != 0) {  // (some sample's result is still open)
+                        if (newacc != 0) {
                             // their costs are exact now: the later samples they are a candidate parent of look again
                             u64 rm = r.rmask & newacc;
                             if (lane < nb && acc0) {
@@ -1593,21 +1604,22 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     }
                     if (lane == 0) par.count = cnt;
                 }
+                DBGT(8);
                 __syncthreads();
-                const uint32_t cnt = par.count;
+                const uint32_t cnt = uni32(par.count);
                 if (cnt == 0) break;
                 if ((uint32_t)wave < cnt) {
-                    const int k = (int)par.list[wave];
+                    const int k = (int)uni32(par.list[wave]);
                     bool acc;
                     double cb;
                     u64 ap[NP];
                     int jp[NP];
 #pragma unroll
                     for (int p2 = 0; p2 < NP; ++p2) {
-                        ap[p2] = par.aprev[p2];
-                        jp[p2] = par.jp0[p2];
+                        ap[p2] = uni64(par.aprev[p2]);
+                        jp[p2] = unis32(par.jp0[p2]);
                     }
-                    resolve_sample(k, par.acc_opt & lowmask64(k), ap, jp, false, acc, cb);
+                    resolve_sample(k, uni64(par.acc_opt) & lowmask64(k), ap, jp, false, acc, cb);
                     if (lane == 0) par.acc[wave] = acc ? 1u : 0u;
                 }
                 __syncthreads();
@@ -1774,6 +1786,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             // state first (write-through), then everything the commit stored, then the flag
             DBGT(9);
             if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0);
+#ifdef RRT_STAMPS_WAITFLAG
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             DBGT(4);
         }
         STAMP(4);
@@ -1781,19 +1796,19 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         DBGT(15);
         {
             const BlkState b = blk;
-            if (G > 1 && b.pad0 != 0) {
+            if (G > 1 && unis32(b.pad0) != 0) {
                 team_failed = true;
                 break;
             }
-            void_next = PIPE && (b.pad1 & ST_FLAG_RESTART) != 0;
+            void_next = PIPE && (unis32(b.pad1) & ST_FLAG_RESTART) != 0;
             prefetched = pre_next;
             if (PIPE && pre_next) bsel ^= 1;
-            i = b.i;
-            j = b.j;
-            nsoln = b.nsoln;
-            vbest_soln = b.vbest_soln;
-            cmin_soln = b.cmin_soln;
-            c_ell = b.c_ell;
+            i = unis32(b.i);
+            j = unis32(b.j);
+            nsoln = unis32(b.nsoln);
+            vbest_soln = unis32(b.vbest_soln);
+            cmin_soln = unif64(b.cmin_soln);
+            c_ell = unif64(b.c_ell);
         }
     }
 
