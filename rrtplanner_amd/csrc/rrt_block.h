@@ -599,7 +599,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     const int kk = (k0 + u) < L ? (k0 + u) : L;
                     int x, y;
                     rrt_line_cell(&ln, kk, &x, &y);
-                    v[u] = og[(size_t)x * H + y];
+                    v[u] = og[(uint32_t)(x * H + y)];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)

@@ -108,7 +108,7 @@ __device__ __forceinline__ bool los_wave(const uint8_t *__restrict__ og, int H, 
         if (lane <= L) {
             int x, y;
             rrt_line_cell(&l, lane, &x, &y);
-            occ = og[(size_t)x * H + y] != 0;
+            occ = og[(uint32_t)(x * H + y)] != 0;
         }
         unsigned long long m = __ballot(occ);
         cells = m ? (int)__builtin_ctzll(m) + 1 : L + 1;
@@ -122,7 +122,7 @@ __device__ __forceinline__ bool los_wave(const uint8_t *__restrict__ og, int H, 
             if (k <= L) {
                 int x, y;
                 rrt_line_cell(&l, k, &x, &y);
-                v[g] = og[(size_t)x * H + y];
+                v[g] = og[(uint32_t)(x * H + y)];
             }
         }
 #pragma unroll
@@ -153,7 +153,7 @@ __device__ __forceinline__ LosPending los_issue(const uint8_t *__restrict__ og, 
     if (l.major < 64 && lane <= l.major) {
         int x, y;
         rrt_line_cell(&l, lane, &x, &y);
-        p.v = og[(size_t)x * H + y];
+        p.v = og[(uint32_t)(x * H + y)];
     }
     return p;
 }
@@ -178,12 +178,12 @@ __device__ __forceinline__ void los_wave2(const uint8_t *__restrict__ og, int H,
         if (lane <= l0.major) {
             int x, y;
             rrt_line_cell(&l0, lane, &x, &y);
-            v0 = og[(size_t)x * H + y];
+            v0 = og[(uint32_t)(x * H + y)];
         }
         if (has1 && lane <= l1.major) {
             int x, y;
             rrt_line_cell(&l1, lane, &x, &y);
-            v1 = og[(size_t)x * H + y];
+            v1 = og[(uint32_t)(x * H + y)];
         }
         const unsigned long long m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
         ok0 = m0 == 0;
@@ -212,7 +212,7 @@ __device__ __forceinline__ void los_batch(const uint8_t *__restrict__ og, int H,
         if (c < nc && lane <= ln[c].major) {
             int x, y;
             rrt_line_cell(&ln[c], lane, &x, &y);
-            v[c] = og[(size_t)x * H + y];
+            v[c] = og[(uint32_t)(x * H + y)];
         }
     }
 #pragma unroll
