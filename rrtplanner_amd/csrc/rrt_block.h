@@ -51,7 +51,10 @@ constexpr int CG = 2;   // cells whose records an owner streams concurrently
 // hanging the device.
 constexpr int TEAM_MAX = 64;
 #ifndef RRT_PIPE_LAG
-#define RRT_PIPE_LAG 2  // blocks a pipelined team's workers run ahead of the commit (RRTStandard / RRTStar; an Informed batch: 1)
+#define RRT_PIPE_LAG 2  // blocks a pipelined team's workers run ahead of the commit (a batch without Informed queries)
+#endif
+#ifndef RRT_PIPE_LAG_INF
+#define RRT_PIPE_LAG_INF 1  // ... when the batch may hold Informed queries (a commit that moves the ellipse voids the blocks in flight)
 #endif
 constexpr int TEAM_BYTES = 36864;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
 constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 3 x 64 */, TEAM_OFF_REC = 1024 /* 3 x 8192 */, TEAM_OFF_ARRIVE = 25600 /* 65 x 128 */, TEAM_OFF_RES = 33920 /* 65 x 16 */;
@@ -201,7 +204,7 @@ struct ParRound {  // pipelined committer: the samples re-resolved side by side,
 // samples of BOTH blocks in flight), one block when the batch may hold Informed queries (a block in flight can be voided).
 template <bool PIPE, bool INF>
 struct PipeShape {
-    static constexpr int LAG = PIPE ? (INF ? 1 : RRT_PIPE_LAG) : 0;
+    static constexpr int LAG = PIPE ? (INF ? RRT_PIPE_LAG_INF : RRT_PIPE_LAG) : 0;
     static constexpr int NP = LAG > 0 ? LAG : 1;      // previous blocks a record / the commit looks at (array extents)
     static constexpr int NSLOT = PIPE ? LAG + 1 : 1;  // record and state buffers in the hand-off area: by block number modulo NSLOT
 };
@@ -720,7 +723,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     constexpr int32_t ST_FLAG_RESTART = 1, ST_FLAG_STOP = 2;
     const bool pipe_inf = PIPE && informed;
     int nprev = 0;            // worker: how many previous blocks exist (their samples are in xqp_lds[0 .. nprev))
-    bool void_next = false;   // committer: the last commit ended early or changed the ellipse
+    int void_turns = 0;       // committer: the last commit ended early or changed the ellipse: the LAG blocks in flight are void
     bool prefetched = false;  // committer: wave 1 fetched this block's samples and records during the last commit
     int bsel = 0;             // committer: which half of brec holds this block's records
     auto publish_state = [&](uint32_t ep, int32_t flags) {  // wave 0 of member 0: state of block `ep`, then its go flag
@@ -766,13 +769,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
         }
         ++epoch;
-        if (PIPE && g == 0 && void_next) {  // the block in flight was resolved for a state that no longer holds: a turn without a commit
+        if (INF && PIPE && g == 0 && void_turns > 0) {  // a block in flight was resolved for a state that no longer holds: a turn without a commit
             if (wave == 0) {
                 const bool ok = team_wait_all(t_arrive, 1, G, epoch, t_fail, lane);
                 if (ok) publish_state(epoch, 0);
                 if (lane == 0) blk.pad0 = ok ? 0 : 1;
             }
-            void_next = false;
+            --void_turns;
 #pragma unroll
             for (int p2 = 0; p2 < NP; ++p2) {
                 A_prev[p2] = 0;
@@ -1800,7 +1803,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 team_failed = true;
                 break;
             }
-            void_next = PIPE && (unis32(b.pad1) & ST_FLAG_RESTART) != 0;
+            if (INF && PIPE && (unis32(b.pad1) & ST_FLAG_RESTART) != 0) void_turns = LAG;
             prefetched = pre_next;
             if (PIPE && pre_next) bsel ^= 1;
             i = unis32(b.i);
