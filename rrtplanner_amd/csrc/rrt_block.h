@@ -188,11 +188,6 @@ union BlkWords {
     u64 w[5];
 };
 
-// PIPE (teams of RRTStandard / RRTStar queries): G workers plus one workgroup that only commits, and a two-deep pipeline --
-// while block s is committed the workers already resolve block s + 1 against the tree as it stood BEFORE block s; every
-// record then also carries the three interaction masks against the samples of block s, and the commit of block s + 1 treats
-// the nodes block s inserted like inserted samples of its own block (their acceptance and costs are exact by then).
-// INF: the batch may hold Informed queries (alg 2); without it everything the ellipse needs is compiled out.
 struct ParRound {  // pipelined committer: the samples re-resolved side by side, one wave each
     u64 acc_opt, aprev[2];
     uint32_t list[NWAVE], acc[NWAVE];
@@ -236,6 +231,13 @@ struct BlockLds {
 // instantiated per role so that neither half carries the other's state through its loop.
 constexpr int ROLE_ALL = 0, ROLE_COMMIT = 1, ROLE_WORK = 2;
 
+// PIPE (teams of 8 and more): G workers plus one workgroup that only commits, and a pipeline of super-blocks -- while block s
+// is committed the workers already resolve block s + 1 (and s + 2: PipeShape::LAG) against the tree as it stood BEFORE block s;
+// every record then also carries the three interaction masks against the samples of each block in flight, and the commit of a
+// block treats the nodes those blocks inserted like inserted samples of its own block (their acceptance and costs are exact
+// by then).
+// INF: the batch may hold Informed queries (alg 2); without it everything the ellipse needs is compiled out.
+
 template <int G, int BSM, bool PIPE, bool INF, int ROLE>
 __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PIPE, INF> &L) {
     static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM <= BS && BSM * G <= 64, "team size");
@@ -275,7 +277,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     if (D->status != ST_RUNNING) return;
     unsigned char *tb = (G > 1) ? bv.team + (size_t)q * TEAM_BYTES : nullptr;
     gu32 *const t_arrive = (gu32 *)(tb + TEAM_OFF_ARRIVE), *const t_go = (gu32 *)(tb + TEAM_OFF_GO), *const t_fail = (gu32 *)(tb + TEAM_OFF_FAIL);
-    gu64 *const t_state = (gu64 *)(tb + TEAM_OFF_STATE), *const t_rec = (gu64 *)(tb + TEAM_OFF_REC);  // PIPE: two of each, by block parity
+    gu64 *const t_state = (gu64 *)(tb + TEAM_OFF_STATE), *const t_rec = (gu64 *)(tb + TEAM_OFF_REC);  // PIPE: NSLOT of each, by block number
     uint32_t epoch = 0;  // super-blocks of this launch so far
     // pre-scan (team members, RRTStandard / RRTStar): while member 0 commits block s, a member already scans the snapshot of
     // block s for the samples of block s + 1; after the commit only the steps that hold the new nodes are scanned again

@@ -44,7 +44,9 @@ print("per-wave owner-phase cyc/iter:", [round(x / a.n) for x in w[:16]])
 print("per-wave near-set part cyc/iter:", [round(x / a.n) for x in w[16:]])
 if os.environ.get("RRT_STAMPS_PIPE"):
     nblk = (a.n + 63) // 64
-    print("committer cyc/block [wait, partA, par round, ordered, publish, n ordered, n par, loop top, record loads, store pass]:", [round(x / nblk, 1) for x in w[:10]])
+    print("committer cyc/block [after the end-of-block barrier, part A, rounds: re-resolutions + barriers, ordered loop, publish, "
+          "wave-0 re-resolutions without near-set redo, samples in rounds, loop top to part A, rounds: lists between them, store pass]:",
+          [round(x / nblk, 1) for x in w[:10]])
     print("committer wave-0 resolves: with near-set redo: %d x %.0f cyc; others: %d x %.0f cyc; rounds/block %.2f" % (w[11], w[10] / max(w[11], 1), w[5], w[12] / max(w[5], 1), w[13] / nblk))
     print("committer: prefetch by wave 1 %.0f cyc/block; wave 0 at the end-of-block barrier %.0f cyc/block" % (w[14] / nblk, w[15] / nblk))
     print("worker 1  cyc/block [resolve, hand over, go wait, take]:", [round(x / nblk, 1) for x in w[16:20]])
