@@ -1586,14 +1586,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                             known |= cb;
                             aknown |= cb & popt;
                         }
-                        lastmask = 0;
-                        while (L0 != 0 && cnt < (uint32_t)NWAVE) {
-                            const int k = __builtin_ctzll(L0);
-                            L0 &= L0 - 1;
-                            lastmask |= 1ull << k;
-                            if (lane == 0) par.list[cnt] = (uint32_t)k;
-                            cnt++;
-                        }
+                        // the first NWAVE of them, in sample order: lane k knows its place in the list
+                        const uint32_t place = (uint32_t)__builtin_popcountll(L0 & ltmask);
+                        const bool listed = ((L0 >> lane) & 1ull) != 0 && place < (uint32_t)NWAVE;
+                        if (listed) par.list[place] = (uint32_t)lane;
+                        lastmask = __ballot(listed);
+                        cnt = (uint32_t)__builtin_popcountll(lastmask);
 #ifdef RRT_STAMPS
                         if (t == 0) dbg[6] += cnt;
                         if (t == 0 && cnt != 0) dbg[13] += 1;
@@ -1640,7 +1638,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #endif
             const int in = i0 + nb;
             const int nbn = (n - in) < SB ? (n - in) : SB;
-            if (lane < nbn) xq_next[lane] = samples[in + lane];
             const bool ok = team_wait_all(t_arrive, 1, G, epoch + 1, t_fail, lane);
             if (ok && lane < nbn) {
                 const gu64 *src = t_rec + (size_t)((epoch + 1) % NSLOT) * 64 * BREC_WORDS + (size_t)lane * BREC_WORDS;
@@ -1653,6 +1650,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #ifdef RRT_STAMPS
             if (lane == 0) dbg[14] += __builtin_amdgcn_s_memtime() - pf0;
 #endif
+        }
+        if (PIPE && wave == 2 && pre_next) {  // (the samples: a wave of their own, one memory round trip less in a row)
+            const int in = i0 + nb;
+            const int nbn = (n - in) < SB ? (n - in) : SB;
+            if (lane < nbn) xq_next[lane] = samples[in + lane];
         }
         // ---- part B (wave 0): decide in order, store, publish ----
         if (wave == 0 && remote_ok) {
