@@ -67,6 +67,14 @@ typedef __attribute__((address_space(1))) u64 gu64;
 
 __device__ __forceinline__ u64 lowmask64(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
 
+// Element idx of a per-query array (all of them are far below 4 GiB): base + zero-extended 32-bit byte offset, which the
+// compiler turns into a scalar base with a 32-bit vector offset instead of keeping a 64-bit copy of the base in vector registers.
+template <class T>
+__device__ __forceinline__ T &at32(T *base, uint32_t idx) {
+    return *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(const_cast<typename std::remove_const<T>::type *>(base)) +
+                                  (size_t)(uint32_t)(idx * (uint32_t)sizeof(T)));
+}
+
 // A value every lane of the wave holds alike (read from LDS or memory): moved to scalar registers, so that it does not
 // take a vector register per lane for as long as it lives.
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -807,7 +815,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 vy = (vy > 0.0) ? vy : 0.0;
                 xv = pack_xy((int)vx, (int)vy);
             } else {
-                xv = (G > 1 && !PIPE && pre_i == i0) ? pre_xv : (PIPE && prefetched) ? xq_next[lane] : samples[i0 + lane];
+                xv = (G > 1 && !PIPE && pre_i == i0) ? pre_xv : (PIPE && prefetched) ? xq_next[lane] : at32(samples, (uint32_t)(i0 + lane));
             }
         }
         if (!worker && t < SB) xq_lds[t] = xv;  // a pipelined team's committer: nothing to resolve
@@ -880,9 +888,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 vs = v.y;
             }
             wave_min_key_idx(d2s, vs);
-            const double Vs = vcost[vs];
+            const double Vs = at32(vcost, vs);
             const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
-            const uint32_t bm_word = bitmap[cell >> 5];
+            const uint32_t bm_word = at32(bitmap, cell >> 5);
             const uint32_t vsxy = node_xy(vs);
             const LosPending lp = los_issue(og, H, vsxy, Xk, lane);  // finished behind the near-set stream
             // earlier samples of this block that could interact once inserted
@@ -937,7 +945,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 vs = v.y;
             }
             wave_min_key_idx(d2s, vs);
-            const double Vs = act ? vcost[vs] : 0.0;
+            const double Vs = act ? at32(vcost, vs) : 0.0;
             const double cnear_s = Vs + sqrt_u32(d2s);
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
@@ -952,7 +960,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             lp.major = 0;
             lp.v = 0;
             if (lead && act) {  // started here, finished behind the near-set stream
-                bm_word = bitmap[cell >> 5];
+                bm_word = at32(bitmap, cell >> 5);
                 vsxy = node_xy(vs);
                 lp = los_issue(og, H, vsxy, Xk, lane);
             }
@@ -1168,7 +1176,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (pipe_inf && ((u.b.pad1 & ST_FLAG_STOP) != 0 || u.b.i >= n)) break;  // the run is over (or waits for the host)
                 const int jn = u.b.j;
                 if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
-                    const uint32_t Xn = nodes_g[j0 + t];
+                    const uint32_t Xn = at32(nodes_g, (uint32_t)(j0 + t));
                     if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
                     if (star) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -1253,7 +1261,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             c_ell = u.b.c_ell;
             const int jn = u.b.j;
             if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
-                const uint32_t Xn = nodes_g[j0 + t];
+                const uint32_t Xn = at32(nodes_g, (uint32_t)(j0 + t));
                 if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
                 if (star) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -1654,7 +1662,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         if (PIPE && wave == 2 && pre_next) {  // (the samples: a wave of their own, one memory round trip less in a row)
             const int in = i0 + nb;
             const int nbn = (n - in) < SB ? (n - in) : SB;
-            if (lane < nbn) xq_next[lane] = samples[in + lane];
+            if (lane < nbn) xq_next[lane] = at32(samples, (uint32_t)(in + lane));
         }
         // ---- part B (wave 0): decide in order, store, publish ----
         if (wave == 0 && remote_ok) {
@@ -1749,17 +1757,17 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         statred[lane * 5 + 3] += f.pstat & 0xfffffu;
                     }
                     const uint32_t cellbit = (uint32_t)ux(xv) * (uint32_t)H + (uint32_t)uy(xv);
-                    nodes_g[jmine] = xv;
+                    at32(nodes_g, (uint32_t)jmine) = xv;
                     if (jmine < lds_nodes) nodes_lds[jmine] = xv;
-                    vcost[jmine] = f.cbest;
-                    parent[jmine] = (int32_t)f.vbest;
-                    atomicOr(&bitmap[cellbit >> 5], 1u << (cellbit & 31));  // rrt.py:426
+                    at32(vcost, (uint32_t)jmine) = f.cbest;
+                    at32(parent, (uint32_t)jmine) = (int32_t)f.vbest;
+                    atomicOr(&at32(bitmap, cellbit >> 5), 1u << (cellbit & 31));  // rrt.py:426
                     if (star) {
                         const int c = cell_of(xv);
                         const uint32_t slot = __hip_atomic_fetch_add(&cellcnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         const unsigned long long cb = (unsigned long long)__double_as_longlong(f.cbest);
                         u32x4 rc = {xv, (uint32_t)jmine, (uint32_t)cb, (uint32_t)(cb >> 32)};
-                        cellrec[(size_t)c * (size_t)ccap + slot] = rc;
+                        at32(cellrec, (uint32_t)c * (uint32_t)ccap + slot) = rc;
                     }
                 }
                 j = j0 + __builtin_popcountll(acc_exact);
