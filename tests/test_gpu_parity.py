@@ -264,7 +264,7 @@ def test_fuzz_small_queries_vs_oracle(gpu_ctx, kernel):
         if free.shape[0] < 2:
             continue
         alg = int(rng.integers(0, 3))
-        n = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 100, 257, 700, 1500]))
+        n = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 192, 193, 257, 700, 1500]))  # (64-sample blocks, up to two in flight)
         rr = float(rng.choice([0, 1, 1.5, 3, 7.9, 12, 25, 64, 500]))
         rg = float(rng.choice([0, 1, 2.5, 6, 15, 100]))
         xs = free[rng.integers(0, free.shape[0])] if case % 11 else np.array([int(rng.integers(0, w)), int(rng.integers(0, h))])
