@@ -198,7 +198,8 @@ union BlkWords {
 
 struct ParRound {  // pipelined committer: the samples re-resolved side by side, one wave each
     u64 acc_opt, aprev[2];
-    uint32_t list[NWAVE], acc[NWAVE];
+    uint32_t list[NWAVE];
+    uint32_t accs[64];  // per sample: inserted by its re-resolution?
     uint32_t count;
     int32_t jp0[2];
 };
@@ -1559,12 +1560,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     uint32_t cnt = 0;
                     u64 newacc = 0;
                     if (lastmask != 0) {  // the samples the last round settled: final, whatever the ordered loop finds
-                        u64 lm = lastmask;
-                        for (uint32_t w = 0; lm != 0; ++w) {
-                            const int k = __builtin_ctzll(lm);
-                            lm &= lm - 1;
-                            if (uni32(par.acc[w]) != 0u) newacc |= 1ull << k;
-                        }
+                        newacc = __ballot(((lastmask >> lane) & 1ull) != 0 && par.accs[lane] != 0u);
                         fin |= lastmask;
                         fin_acc |= newacc;
                         known |= lastmask;
@@ -1631,7 +1627,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         jp[p2] = unis32(par.jp0[p2]);
                     }
                     resolve_sample(k, uni64(par.acc_opt) & lowmask64(k), ap, jp, false, acc, cb);
-                    if (lane == 0) par.acc[wave] = acc ? 1u : 0u;
+                    if (lane == 0) par.accs[k] = acc ? 1u : 0u;
                 }
                 __syncthreads();
             }
