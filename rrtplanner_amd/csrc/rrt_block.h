@@ -816,7 +816,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 vy = (vy > 0.0) ? vy : 0.0;
                 xv = pack_xy((int)vx, (int)vy);
             } else {
-                xv = (G > 1 && !PIPE && pre_i == i0) ? pre_xv : (PIPE && prefetched) ? xq_next[lane] : at32(samples, (uint32_t)(i0 + lane));
+                if (PIPE && prefetched) xv = xq_next[lane];  // (a branch of its own: merged with the global load it becomes a flat load)
+                else xv = (G > 1 && !PIPE && pre_i == i0) ? pre_xv : at32(samples, (uint32_t)(i0 + lane));
             }
         }
         if (!worker && t < SB) xq_lds[t] = xv;  // a pipelined team's committer: nothing to resolve
