@@ -1176,7 +1176,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #pragma unroll
                 for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + (size_t)((epoch - LAG) % NSLOT) * 8 + w, RRT_RLX_AGENT);
                 if (pipe_inf && ((u.b.pad1 & ST_FLAG_STOP) != 0 || u.b.i >= n)) break;  // the run is over (or waits for the host)
-                const int jn = u.b.j;
+                const int jn = unis32(u.b.j);
                 if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
                     const uint32_t Xn = at32(nodes_g, (uint32_t)(j0 + t));
                     if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
@@ -1184,10 +1184,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 j = jn;
                 if (pipe_inf) {
-                    nsoln = u.b.nsoln;
-                    vbest_soln = u.b.vbest_soln;
-                    cmin_soln = u.b.cmin_soln;
-                    c_ell = u.b.c_ell;
+                    nsoln = unis32(u.b.nsoln);
+                    vbest_soln = unis32(u.b.vbest_soln);
+                    cmin_soln = unif64(u.b.cmin_soln);
+                    c_ell = unif64(u.b.c_ell);
                     if ((u.b.pad1 & ST_FLAG_RESTART) != 0) {
                         // that commit ended early or moved the ellipse: the block just handed over is void; wait for the
                         // committer's empty turn, then start over from the true state without a previous block
@@ -1205,7 +1205,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #pragma unroll
                         for (int w = 0; w < 5; ++w) u2.w[w] = __hip_atomic_load(t_state + (size_t)(epoch % NSLOT) * 8 + w, RRT_RLX_AGENT);
                         if ((u2.b.pad1 & ST_FLAG_STOP) != 0) break;
-                        i = u.b.i;
+                        i = unis32(u.b.i);
                         nprev = 0;
                     }
                 }
@@ -1256,12 +1256,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             BlkWords u;
 #pragma unroll
             for (int w = 0; w < 5; ++w) u.w[w] = __hip_atomic_load(t_state + w, RRT_RLX_AGENT);  // vector loads past the L1
-            i = u.b.i;
-            nsoln = u.b.nsoln;
-            vbest_soln = u.b.vbest_soln;
-            cmin_soln = u.b.cmin_soln;
-            c_ell = u.b.c_ell;
-            const int jn = u.b.j;
+            i = unis32(u.b.i);
+            nsoln = unis32(u.b.nsoln);
+            vbest_soln = unis32(u.b.vbest_soln);
+            cmin_soln = unif64(u.b.cmin_soln);
+            c_ell = unif64(u.b.c_ell);
+            const int jn = unis32(u.b.j);
             if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
                 const uint32_t Xn = at32(nodes_g, (uint32_t)(j0 + t));
                 if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
