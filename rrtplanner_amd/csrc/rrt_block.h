@@ -817,7 +817,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 xv = pack_xy((int)vx, (int)vy);
             } else {
                 if (PIPE && prefetched) xv = xq_next[lane];  // (a branch of its own: merged with the global load it becomes a flat load)
-                else xv = (G > 1 && !PIPE && pre_i == i0) ? pre_xv : at32(samples, (uint32_t)(i0 + lane));
+                else xv = (G > 1 && pre_i == i0) ? pre_xv : at32(samples, (uint32_t)(i0 + lane));
             }
         }
         if (!worker && t < SB) xq_lds[t] = xv;  // a pipelined team's committer: nothing to resolve
@@ -836,7 +836,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         {
             uint32_t best[BSM];
             int c_first = 0;
-            if (G > 1 && !PIPE && pre_i == i0) {  // steps [0, pre_j) were scanned while member 0 committed; unfilled slots held node 0
+            if (G > 1 && pre_i == i0) {  // steps [0, pre_j) were scanned while member 0 committed; unfilled slots held node 0
                 c_first = pre_j / CHUNK;
 #pragma unroll
                 for (int k = 0; k < BSM; ++k) best[k] = pre_best[k];
@@ -1151,6 +1151,28 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
                 }
                 if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
+            }
+            // The commit this worker has to take next is some way off: meanwhile it scans the nodes it already has for the NEXT
+            // block's samples (known: only an Informed block can be cut short); after the take only the steps that hold new
+            // nodes are left.
+            pre_i = -1;
+            if (!informed && more) {
+                pre_i = i0 + nb;
+                pre_j = j0;
+                const int nbn = (n - pre_i) < SB ? (n - pre_i) : SB;
+                pre_xv = lane < nbn ? at32(samples, (uint32_t)(pre_i + lane)) : 0u;
+                uint32_t xsn[BSM];
+#pragma unroll
+                for (int k = 0; k < BSM; ++k) {
+                    const int sk = wg * BSM + k;
+                    uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)pre_xv, sk);
+                    if (sk >= nbn) X = (uint32_t)__builtin_amdgcn_readlane((int)pre_xv, 0);
+                    xsn[k] = X << 4;
+                    pre_best[k] = NONE;
+                }
+                scan_steps(0, pre_j / CHUNK, pre_j, xsn, pre_best);
+            }
+            if (wave == 0) {
                 bool ok = true;
                 DBGT(1);
                 if (take) {
