@@ -1314,13 +1314,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // before the snapshot's choice: cost-through-it < cost through the snapshot parent (ties go to the lower index = the
         // snapshot, rrt.py:518-521).  A single-precision bound settles almost every pair; bit k is re-evaluated when sample
         // k's cost becomes exact.
-        auto harmful = [&](int kk) -> bool {
-            const uint32_t d2 = dist2(xq_lds[kk], xv);
-            const double nc = newcost[kk];
-            const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
-            if (low >= screen_of(r.cbest)) return false;
-            return nc + sqrt_u32(d2) < r.cbest;
+        // nc + sqrt(d2) < cb, decided in single precision on either side whenever the margin allows (|error| of the f32 sum
+        // < 1e-3 below 2^12 + relative 2e-7): the f64 square root only runs for close calls.
+        auto cheaper_through = [&](double nc, uint32_t d2, double cb) -> bool {
+            const float f = (float)nc + __builtin_amdgcn_sqrtf((float)d2), cf = (float)cb;
+            if (f * (1.0f - 1.0e-6f) - 4.0e-3f >= cf * (1.0f + 1.0e-6f) + 4.0e-3f) return false;
+            if (f * (1.0f + 1.0e-6f) + 4.0e-3f < cf * (1.0f - 1.0e-6f) - 4.0e-3f) return true;
+            return nc + sqrt_u32(d2) < cb;
         };
+        auto harmful = [&](int kk) -> bool { return cheaper_through(newcost[kk], dist2(xq_lds[kk], xv), r.cbest); };
         // Sample k on its own, re-resolved against snapshot + inserted nodes of this block (accepted: acc_k) and of the previous
         // ones (ap[], their count bases jp[]): any wave.  Its record in LDS is replaced by the final one; returns acceptance and cost.
         // Block references: 0x80000000 + 64 * set + kk with set 0 = the oldest previous block ... NP = this block.
@@ -1545,10 +1547,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                             while (rm) {
                                 const int kk = __builtin_ctzll(rm);
                                 rm &= rm - 1;
-                                const uint32_t d2 = dist2(xqp_lds[p2][kk], xv);
-                                const double nc = prevcost[p2][kk];
-                                const float low = ((float)nc + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
-                                if (low < screen_of(r.cbest) && nc + sqrt_u32(d2) < r.cbest) pbad = true;
+                                if (cheaper_through(prevcost[p2][kk], dist2(xqp_lds[p2][kk], xv), r.cbest)) pbad = true;
                             }
                         }
                     }
