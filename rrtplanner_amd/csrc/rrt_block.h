@@ -54,7 +54,7 @@ constexpr int TEAM_MAX = 64;
 #define RRT_PIPE_LAG 2  // blocks a pipelined team's workers run ahead of the commit (a batch without Informed queries)
 #endif
 #ifndef RRT_PIPE_LAG_INF
-#define RRT_PIPE_LAG_INF 1  // ... when the batch may hold Informed queries (a commit that moves the ellipse voids the blocks in flight)
+#define RRT_PIPE_LAG_INF 2  // ... when the batch may hold Informed queries (a commit that moves the ellipse voids the blocks in flight)
 #endif
 constexpr int TEAM_BYTES = 36864;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
 constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 3 x 64 */, TEAM_OFF_REC = 1024 /* 3 x 8192 */, TEAM_OFF_ARRIVE = 25600 /* 65 x 128 */, TEAM_OFF_RES = 33920 /* 65 x 16 */;
@@ -204,8 +204,8 @@ struct ParRound {  // pipelined committer: the samples re-resolved side by side,
     int32_t jp0[2];
 };
 
-// How far the workers run ahead of the commit: two blocks (RRTStandard / RRTStar: every record carries masks against the
-// samples of BOTH blocks in flight), one block when the batch may hold Informed queries (a block in flight can be voided).
+// How far the workers run ahead of the commit: two blocks (every record carries masks against the samples of BOTH blocks in
+// flight; a commit of an Informed query that ends early or moves the ellipse voids both).
 template <bool PIPE, bool INF>
 struct PipeShape {
     static constexpr int LAG = PIPE ? (INF ? RRT_PIPE_LAG_INF : RRT_PIPE_LAG) : 0;
@@ -735,7 +735,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     const bool pipe_inf = PIPE && informed;
     int nprev = 0;            // worker: how many previous blocks exist (their samples are in xqp_lds[0 .. nprev))
     int void_turns = 0;       // committer: the last commit ended early or changed the ellipse: the LAG blocks in flight are void
-    bool prefetched = false;  // committer: wave 1 fetched this block's samples and records during the last commit
+    bool prefetched = false;  // committer: wave 1 fetched this block's records during the last commit ...
+    bool prefetched_smp = false;  // ... and wave 2 its samples (not those of an Informed query: the ellipse may move)
     int bsel = 0;             // committer: which half of brec holds this block's records
     auto publish_state = [&](uint32_t ep, int32_t flags) {  // wave 0 of member 0: state of block `ep`, then its go flag
         if (lane == 0) {
@@ -787,6 +788,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (lane == 0) blk.pad0 = ok ? 0 : 1;
             }
             --void_turns;
+            prefetched = prefetched_smp = false;  // (whatever was fetched belonged to the void block)
 #pragma unroll
             for (int p2 = 0; p2 < NP; ++p2) {
                 A_prev[p2] = 0;
@@ -816,7 +818,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 vy = (vy > 0.0) ? vy : 0.0;
                 xv = pack_xy((int)vx, (int)vy);
             } else {
-                if (PIPE && prefetched) xv = xq_next[lane];  // (a branch of its own: merged with the global load it becomes a flat load)
+                if (PIPE && prefetched_smp) xv = xq_next[lane];  // (a branch of its own: merged with the global load it becomes a flat load)
                 else xv = (G > 1 && pre_i == i0) ? pre_xv : at32(samples, (uint32_t)(i0 + lane));
             }
         }
@@ -1657,7 +1659,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         DBGT(2);
         // A pipelined committer's wave 1 meanwhile fetches the next block: its samples, and (workers that run ahead have
         // handed them over already) its records.  Only an Informed block can end early, so the next block is known.
-        const bool pre_next = PIPE && !informed && i0 + nb < n;
+        const bool pre_next = PIPE && (!informed || LAG >= 2) && i0 + nb < n;
+        const bool pre_smp = pre_next && !informed;
         if (PIPE && wave == 1 && pre_next) {
 #ifdef RRT_STAMPS
             const unsigned long long pf0 = __builtin_amdgcn_s_memtime();
@@ -1677,7 +1680,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (lane == 0) dbg[14] += __builtin_amdgcn_s_memtime() - pf0;
 #endif
         }
-        if (PIPE && wave == 2 && pre_next) {  // (the samples: a wave of their own, one memory round trip less in a row)
+        if (PIPE && wave == 2 && pre_smp) {  // (the samples: a wave of their own, one memory round trip less in a row)
             const int in = i0 + nb;
             const int nbn = (n - in) < SB ? (n - in) : SB;
             if (lane < nbn) xq_next[lane] = at32(samples, (uint32_t)(in + lane));
@@ -1835,6 +1838,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
             if (INF && PIPE && (unis32(b.pad1) & ST_FLAG_RESTART) != 0) void_turns = LAG;
             prefetched = pre_next;
+            prefetched_smp = pre_smp;
             if (PIPE && pre_next) bsel ^= 1;
             i = unis32(b.i);
             j = unis32(b.j);
