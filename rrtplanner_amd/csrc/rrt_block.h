@@ -1406,7 +1406,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 const double cnear = cbest;
                 if (nn_inblock) {
                     const double cnear_s = rk.Vs + sqrt_u32(rk.d2s);
-                    if (cnear > cnear_s) {  // entries between the two bounds were never priced: redo the snapshot part
+                    if (cnear > cnear_s && pi == NONE) {  // entries between the two bounds were never priced: redo the snapshot
+                                                          // part (a parent found below the old bound stays the cheapest: same tests)
                         ntests = 0;
                         tcells = 0;
 #ifdef RRT_STAMPS
