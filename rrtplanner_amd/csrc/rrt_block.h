@@ -1823,9 +1823,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             // state first (write-through), then everything the commit stored, then the flag
             DBGT(9);
             if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0);
-#ifdef RRT_STAMPS_WAITFLAG
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             DBGT(4);
         }
         STAMP(4);
