@@ -27,8 +27,8 @@ extern "C" {
 #define RRT_E_GOAL_UNREACHABLE (-2) /* rrt.py:317-318 would index og[INT64_MIN,..]: no line of sight, j < n */
 #define RRT_E_HIP (-3)
 #define RRT_E_NOGRID (-4)
-#define RRT_E_UNSUPPORTED (-5)     /* grid larger than 2048 x 2048 (packed-key fast path), n > 262144 */
-#define RRT_E_COMM (-6)
+#define RRT_E_UNSUPPORTED (-5)     /* grid larger than 2048 x 2048 (packed-key fast path), n > 262143 */
+#define RRT_E_COMM (-6)            /* multi-GPU gather: librccl missing, no communicator, RCCL error, unequal slabs */
 
 #define RRT_ALG_STANDARD 0 /* RRTStandard.plan     rrt.py:386 */
 #define RRT_ALG_STAR 1     /* RRTStar.plan         rrt.py:466 */
@@ -100,6 +100,11 @@ int rrt_noise_grids(rrt_ctx *ctx, int32_t W, int32_t H, int32_t frames, float th
                     const double *cells, const double *amps, const double *grads, uint8_t *og_out);
 /* make frame k of the resident noise grids the active grid (no upload; anim.py:92-93 style replanning) */
 int rrt_select_frame(rrt_ctx *ctx, int32_t frame);
+/* counts the calls that rewrote the context's grid storage (rrt_set_grid, rrt_noise_grids).  A caller that keeps frames
+ * resident records it after rrt_noise_grids and compares before rrt_select_frame: a different value means the frames are gone. */
+int rrt_grid_generation(rrt_ctx *ctx, uint64_t *generation);
+/* wait for everything queued on the context's stream and on its device */
+int rrt_ctx_sync(rrt_ctx *ctx);
 
 /* ---- resident batches: Q independent queries on the ctx's grid ------------------------- */
 int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t flags, rrt_batch **out);
@@ -110,18 +115,37 @@ int rrt_batch_set_unitball(rrt_batch *b, int32_t q, const double *unitball, int3
 int rrt_batch_rearm(rrt_batch *b);  /* reset every query's tree, keep the uploaded inputs */
 int rrt_batch_launch(rrt_batch *b); /* asynchronous on the ctx stream; runs / resumes every unfinished query */
 int rrt_batch_sync(rrt_batch *b);
-/* CUs working on each query (team size; 1 after a fallback) and how often a team hand-off timed out */
+/* CUs working on each query (the team size chosen at rrt_batch_create) and how often a team hand-off timed out: such a launch
+ * is continued once with one CU per query, the next launch uses the team again */
 int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fallbacks);
 /* 1 if the last launch ran the pipelined team kernel (one more CU per query, which only commits) */
 int rrt_batch_pipelined(rrt_batch *b, int32_t *pipelined);
-int rrt_batch_elapsed_ms(rrt_batch *b, float *ms); /* HIP events around the last launch's kernels */
+int rrt_batch_elapsed_ms(rrt_batch *b, float *ms); /* HIP events around the last launch's kernels (incl. a launch that timed out) */
 int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out);
 /* diagnostic builds (-DRRT_STAMPS): shader cycles wave 0 of query q spent in scan / barrier / nearest+line of sight /
  * choose parent / insert / go2goal; zeros in the product build */
 int rrt_batch_debug_cycles(rrt_batch *b, int32_t q, uint64_t out[38]); /* [0..5] phases, [6..37] per-wave owner-phase cycles */
-/* device-resident result slab of the batch: [vcost f64 | nodes u32 (x | y<<16) | parent i32], each [Q][stride],
- * stride = bytes / (16 Q)  (for the multi-GPU gather) */
+/* device-resident result slab of the batch: [vcost f64 | nodes u32 (x | y<<16) | parent i32], each [Q][stride], then
+ * {status, j, vgoal, found} i32 per query (filled by rrt_gather); stride = (bytes - 16 Q) / (16 Q) */
 int rrt_batch_result_block(rrt_batch *b, void **dev_ptr, int64_t *bytes);
+
+/* ---- multi-GPU: one process per GPU, query q on rank q mod world (no data-path collective), one all-gather of the result
+ * slabs over RCCL / xGMI at the end of a batch.  The reference has no counterpart (single process).
+ * librccl is opened on the first of these calls; the single-GPU path never loads it. ---- */
+#define RRT_COMM_ID_BYTES 128
+/* rank 0: a fresh communicator id (ncclGetUniqueId); the host ships the bytes to the other ranks over any side channel */
+int rrt_comm_unique_id(uint8_t id[RRT_COMM_ID_BYTES]);
+/* collective over all `world` ranks (ncclCommInitRank on the context's device) */
+int rrt_comm_init(rrt_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[RRT_COMM_ID_BYTES]);
+int rrt_comm_destroy(rrt_ctx *ctx);
+/* vals[0..count) := reduction over all ranks (op 0 sum, 1 max, 2 min), count <= 64; synchronous: also the barrier */
+int rrt_comm_allreduce_f64(rrt_ctx *ctx, double *vals, int32_t count, int32_t op);
+/* ncclAllGather of the batch's result slab on the context's stream (asynchronous): rank r's slab lands at
+ * gathered_dev + r * bytes_per_rank on every rank.  Every rank must bring a batch of the same Q and capacity. */
+int rrt_gather(rrt_batch *b, void **gathered_dev, int64_t *bytes_per_rank);
+/* after rrt_gather: query q of rank `rank` from the gathered slabs into caller-allocated host arrays (pts / vcost / parent
+ * with n+1 rows as in rrt_batch_get_result; status, j, vgoal, found are filled; logs and statistics are not gathered) */
+int rrt_gather_fetch(rrt_batch *b, int32_t rank, int32_t q, rrt_result *out);
 
 /* ---- one-shot wrappers (what plan() binds) --------------------------------------------- */
 int rrt_plan(rrt_ctx *ctx, const rrt_query *query, uint32_t flags, rrt_result *out);

@@ -46,6 +46,8 @@ def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=Tru
 # every symbol include/rrt_hip.h declares (tests/test_capi_symbols.py checks the library exports them)
 SYMBOLS = (
     "rrt_ctx_create", "rrt_ctx_destroy", "rrt_last_error_string", "rrt_set_grid", "rrt_noise_grids", "rrt_select_frame",
+    "rrt_grid_generation", "rrt_ctx_sync",
+    "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_comm_allreduce_f64", "rrt_gather", "rrt_gather_fetch",
     "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
     "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_pipelined", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
@@ -102,6 +104,14 @@ def lib():
             "rrt_set_grid": ([vp, vp, i32, i32], C.c_int),
             "rrt_noise_grids": ([vp, i32, i32, i32, C.c_float, i32, vp, vp, vp, vp, vp], C.c_int),
             "rrt_select_frame": ([vp, i32], C.c_int),
+            "rrt_grid_generation": ([vp, C.POINTER(C.c_uint64)], C.c_int),
+            "rrt_ctx_sync": ([vp], C.c_int),
+            "rrt_comm_unique_id": ([vp], C.c_int),
+            "rrt_comm_init": ([vp, i32, i32, vp], C.c_int),
+            "rrt_comm_destroy": ([vp], C.c_int),
+            "rrt_comm_allreduce_f64": ([vp, vp, i32, i32], C.c_int),
+            "rrt_gather": ([vp, C.POINTER(vp), C.POINTER(i64)], C.c_int),
+            "rrt_gather_fetch": ([vp, i32, i32, C.POINTER(Result)], C.c_int),
             "rrt_batch_create": ([vp, i32, i32, u32, C.POINTER(vp)], C.c_int),
             "rrt_batch_destroy": ([vp], C.c_int),
             "rrt_batch_set_query": ([vp, i32, C.POINTER(Query)], C.c_int),
@@ -137,6 +147,16 @@ def _check(ctx_handle, rc, ok=(RRT_OK,)):
         return rc
     msg = lib().rrt_last_error_string(ctx_handle)
     raise RRTError(rc, msg.decode() if msg else "")
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """A fresh RCCL communicator id (rank 0 creates it and ships it to the other ranks, see multi.exchange_unique_id)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(None, lib().rrt_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf)
 
 
 class ResultArrays:
@@ -230,6 +250,37 @@ class Context:
     def select_frame(self, k):
         _check(self._h, lib().rrt_select_frame(self._h, int(k)))
 
+    def grid_generation(self):
+        """How often the context's grid storage has been rewritten (set_grid / noise_grids); resident frames are only
+        valid while this has the value it had right after they were generated."""
+        g = C.c_uint64(0)
+        _check(self._h, lib().rrt_grid_generation(self._h, C.byref(g)))
+        return g.value
+
+    def sync(self):
+        _check(self._h, lib().rrt_ctx_sync(self._h))
+
+    # ---- multi-GPU (RCCL) ----
+    def comm_init(self, rank, world, unique_id: bytes):
+        """Collective: join the communicator `unique_id` (comm_unique_id() of rank 0) as `rank` of `world`."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique id must have {COMM_ID_BYTES} bytes")
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self._h, lib().rrt_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_destroy(self):
+        _check(self._h, lib().rrt_comm_destroy(self._h))
+
+    def allreduce(self, values, op="sum"):
+        """All-reduce a few float64 values over the ranks (sum / max / min); synchronous, so it doubles as the barrier."""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        _check(self._h, lib().rrt_comm_allreduce_f64(self._h, v.ctypes.data, v.size, {"sum": 0, "max": 1, "min": 2}[op]))
+        return v
+
+    def barrier(self):
+        self.allreduce([0.0])
+
     # ---- one-shot ----
     def plan(self, query, n, logs=False, serial=False, team=None, team_fault=False, pipe=True):
         res = ResultArrays(n, logs)
@@ -243,6 +294,19 @@ class Context:
         rc = lib().rrt_plan_resume(self._h, ub.ctypes.data, ub.shape[0], C.byref(res.c))
         _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
         return rc
+
+    def plan_batch(self, queries, ns):
+        """rrt_plan_batch: Q independent queries on this context's grid in one call (RRTStandard / RRTStar; an Informed
+        query stops at RRT_NEED_UNITBALL -- use Batch for the staged hand-over).  Returns (rc, [ResultArrays])."""
+        Q = len(queries)
+        qarr = (Query * Q)(*queries)
+        res = [ResultArrays(int(n)) for n in ns]
+        rarr = (Result * Q)(*[r.c for r in res])
+        rc = lib().rrt_plan_batch(self._h, Q, qarr, rarr)
+        _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
+        for r, c in zip(res, rarr):
+            r.c = c
+        return rc, res
 
     # ---- primitives ----
     def prim_collisionfree(self, ab):
@@ -359,3 +423,16 @@ class Batch:
         p, nbytes = C.c_void_p(), C.c_int64()
         _check(self.ctx.handle, lib().rrt_batch_result_block(self._h, C.byref(p), C.byref(nbytes)))
         return p.value, nbytes.value
+
+    def gather(self):
+        """All-gather the result slabs of this batch over the context's communicator (asynchronous on its stream).
+        Returns (device pointer of the gathered slabs, bytes per rank)."""
+        p, nbytes = C.c_void_p(), C.c_int64()
+        _check(self.ctx.handle, lib().rrt_gather(self._h, C.byref(p), C.byref(nbytes)))
+        return p.value, nbytes.value
+
+    def gather_fetch(self, rank, q, n=None):
+        """Query q of rank `rank` out of the gathered slabs (host arrays; status / j / vgoal / found filled)."""
+        res = ResultArrays(self.n_cap if n is None else int(n))
+        _check(self.ctx.handle, lib().rrt_gather_fetch(self._h, int(rank), int(q), C.byref(res.c)))
+        return res

@@ -1,6 +1,8 @@
 // rrt_engine.hip -- C ABI (include/rrt_hip.h) over the gfx950 kernels of rrt_kernels.h.
 // Host side: HIP memory, one stream per context, events for kernel timing.  No torch.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is opened on demand (rrt_comm_init), the single-GPU path never loads it
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -32,6 +34,13 @@ struct rrt_ctx {
     uint32_t single_flags = 0;
     int max_lds = 0;
     int num_cu = 0;
+    uint64_t grid_gen = 0;  // bumped by every call that rewrites or reallocates og_buf (rrt_set_grid, rrt_noise_grids)
+    // multi-GPU result gather (RCCL over xGMI); all null / 1 until rrt_comm_init
+    ncclComm_t comm = nullptr;
+    int32_t comm_rank = 0, comm_world = 1;
+    unsigned char *gather_buf = nullptr;  // [world][slab bytes of the batch gathered last]
+    size_t gather_bytes = 0;
+    double *d_red = nullptr;  // small device scratch of rrt_comm_allreduce_f64
 };
 
 struct rrt_batch {
@@ -61,6 +70,8 @@ struct rrt_batch {
     size_t slab_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    float ms_before = 0.f;      // kernel time of the launch a fallback relaunch replaced (rrt_batch_elapsed_ms adds it)
+    bool one_cu_once = false;   // the next launch runs one CU per query whatever b->team says (continuation after a timeout)
     std::vector<uint32_t> stage;  // host staging for packed samples
 };
 
@@ -84,6 +95,23 @@ static int fail(rrt_ctx *ctx, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, RRT_E_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
     } while (0)
 
+// device temporaries of one call: freed on every return path
+struct DevTmp {
+    std::vector<void *> ptrs;
+    ~DevTmp() {
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    hipError_t alloc(T **out, size_t bytes) {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return e;
+    }
+};
+
 extern "C" const char *rrt_last_error_string(rrt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
 extern "C" int rrt_ctx_create(int32_t device_id, rrt_ctx **out) {
@@ -95,9 +123,14 @@ extern "C" int rrt_ctx_create(int32_t device_id, rrt_ctx **out) {
     HIPCHK(nullptr, hipSetDevice(device_id));
     rrt_ctx *c = new rrt_ctx();
     c->device = device_id;
-    HIPCHK(nullptr, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(nullptr, hipDeviceGetAttribute(&c->max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id));
-    HIPCHK(nullptr, hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device_id));
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&c->max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device_id);
+    if (e != hipSuccess) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(nullptr, RRT_E_HIP, "rrt_ctx_create: %s", hipGetErrorString(e));
+    }
     *out = c;
     return RRT_OK;
 }
@@ -106,6 +139,7 @@ extern "C" int rrt_ctx_destroy(rrt_ctx *ctx) {
     if (!ctx) return RRT_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->single) rrt_batch_destroy(ctx->single);
+    (void)rrt_comm_destroy(ctx);
     if (ctx->og_buf) (void)hipFree(ctx->og_buf);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -119,6 +153,8 @@ extern "C" int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->og_buf && ctx->og_buf_bytes != (size_t)W * H) {
+        ctx->grid_gen += 1;
+        ctx->og = nullptr;
         HIPCHK(ctx, hipFree(ctx->og_buf));
         ctx->og_buf = nullptr;
     }
@@ -128,6 +164,7 @@ extern "C" int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, 
     }
     ctx->og = ctx->og_buf;
     ctx->nframes = 1;
+    ctx->grid_gen += 1;
     HIPCHK(ctx, hipMemcpyAsync(ctx->og, og_nonzero, (size_t)W * H, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->W = W;
@@ -216,6 +253,8 @@ extern "C" int rrt_noise_grids(rrt_ctx *ctx, int32_t W, int32_t H, int32_t frame
         ngrad += (size_t)nz * nx * ny * 3;
     }
     if (ctx->og_buf && ctx->og_buf_bytes != total) {
+        ctx->grid_gen += 1;
+        ctx->og = nullptr;
         HIPCHK(ctx, hipFree(ctx->og_buf));
         ctx->og_buf = nullptr;
     }
@@ -223,16 +262,18 @@ extern "C" int rrt_noise_grids(rrt_ctx *ctx, int32_t W, int32_t H, int32_t frame
         HIPCHK(ctx, hipMalloc(&ctx->og_buf, total));
         ctx->og_buf_bytes = total;
     }
+    ctx->grid_gen += 1;  // og_buf is rewritten (and possibly reallocated) from here on
+    DevTmp tmp;
     int32_t *d_dims = nullptr;
     double *d_cells = nullptr, *d_amps = nullptr, *d_grads = nullptr;
     float *d_val = nullptr;
     uint32_t *d_mm = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_dims, (size_t)octaves * 3 * sizeof(int32_t)));
-    HIPCHK(ctx, hipMalloc((void **)&d_cells, (size_t)octaves * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_amps, (size_t)octaves * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_grads, ngrad * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_val, total * sizeof(float)));
-    HIPCHK(ctx, hipMalloc((void **)&d_mm, 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, tmp.alloc(&d_dims, (size_t)octaves * 3 * sizeof(int32_t)));
+    HIPCHK(ctx, tmp.alloc(&d_cells, (size_t)octaves * sizeof(double)));
+    HIPCHK(ctx, tmp.alloc(&d_amps, (size_t)octaves * sizeof(double)));
+    HIPCHK(ctx, tmp.alloc(&d_grads, ngrad * sizeof(double)));
+    HIPCHK(ctx, tmp.alloc(&d_val, total * sizeof(float)));
+    HIPCHK(ctx, tmp.alloc(&d_mm, 2 * sizeof(uint32_t)));
     const uint32_t mm0[2] = {0xffffffffu, 0u};
     HIPCHK(ctx, hipMemcpyAsync(d_dims, dims, (size_t)octaves * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_cells, cells, (size_t)octaves * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -246,11 +287,16 @@ extern "C" int rrt_noise_grids(rrt_ctx *ctx, int32_t W, int32_t H, int32_t frame
     HIPCHK(ctx, hipGetLastError());
     if (og_out) HIPCHK(ctx, hipMemcpyAsync(og_out, ctx->og_buf, total, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (void *p : {(void *)d_dims, (void *)d_cells, (void *)d_amps, (void *)d_grads, (void *)d_val, (void *)d_mm}) HIPCHK(ctx, hipFree(p));
     ctx->W = W;
     ctx->H = H;
     ctx->nframes = frames;
     ctx->og = ctx->og_buf;
+    return RRT_OK;
+}
+
+extern "C" int rrt_grid_generation(rrt_ctx *ctx, uint64_t *generation) {
+    if (!ctx || !generation) return fail(ctx, RRT_E_ARG, "rrt_grid_generation: NULL");
+    *generation = ctx->grid_gen;
     return RRT_OK;
 }
 
@@ -330,7 +376,9 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         // L2); larger teams use stride = 4 / 2 (mod 8): two / four XCDs with 16 members each.  Placement is speed only.
         int want = (int)((flags >> 8) & 0x7fu);
         if (want == 0) want = TEAM_MAX;
-        if (const char *e = getenv("RRT_TEAM")) want = atoi(e);  // experiments: cap the team size
+#ifdef RRT_STAMPS
+        if (const char *e = getenv("RRT_TEAM")) want = atoi(e);  // diagnostic build only: cap the team size
+#endif
         b->team = 1;
         b->team_qpad = (Q + 7) & ~7;
         int pipe_team = 0, pipe_stride = 0;  // the largest team of 8+ that also has room for its committer (pipelined)
@@ -379,7 +427,8 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     } while (0)
     ALLOC(b->d_desc, q * sizeof(QDesc));
     ALLOC(b->d_samples, q * n_cap * sizeof(uint32_t));
-    b->slab_bytes = q * b->node_stride * (sizeof(double) + sizeof(uint32_t) + sizeof(int32_t));
+    // [vcost f64 | nodes u32 | parent i32][Q][node_stride], then {status, j, vgoal, found} i32 per query (written by rrt_gather)
+    b->slab_bytes = q * b->node_stride * (sizeof(double) + sizeof(uint32_t) + sizeof(int32_t)) + q * 4 * sizeof(int32_t);
     ALLOC(b->d_slab, b->slab_bytes);
     b->d_vcost = reinterpret_cast<double *>(b->d_slab);
     b->d_nodes = reinterpret_cast<uint32_t *>(b->d_slab + q * b->node_stride * sizeof(double));
@@ -398,11 +447,15 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         ALLOC(b->d_j_log, q * n_cap * sizeof(int32_t));
     }
 #undef ALLOC
-    HIPCHK(ctx, hipMemsetAsync(b->d_slab, 0, b->slab_bytes, ctx->stream));
-    HIPCHK(ctx, hipEventCreate(&b->ev0));
-    HIPCHK(ctx, hipEventCreate(&b->ev1));
-    HIPCHK(ctx, hipMemcpyAsync(b->d_desc, b->h_desc.data(), q * sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipMemsetAsync(b->d_slab, 0, b->slab_bytes, ctx->stream);
+    if (e == hipSuccess) e = hipEventCreate(&b->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+    if (e == hipSuccess) e = hipMemcpyAsync(b->d_desc, b->h_desc.data(), q * sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        rrt_batch_destroy(b);
+        return fail(ctx, RRT_E_HIP, "rrt_batch_create: %s", hipGetErrorString(e));
+    }
     *out = b;
     return RRT_OK;
 }
@@ -556,15 +609,18 @@ static block_kernel_fn block_kernel_fn_of(int team, bool pipe, bool inf) {
 
 static const void *block_kernel_of(int team, bool pipe, bool inf) { return reinterpret_cast<const void *>(block_kernel_fn_of(team, pipe, inf)); }
 
+// static LDS of the kernels a batch of this team size may launch: its own variants and the one-CU kernel that continues
+// a batch after a hand-off timed out (rrt_batch_sync)
 static size_t block_kernel_static_lds(int team) {
     hipFuncAttributes a{};
     size_t worst = 0;
-    for (bool pipe : {false, true})
-        for (bool inf : {false, true}) {
-            if (pipe && team < 8) continue;
-            if (hipFuncGetAttributes(&a, block_kernel_of(team, pipe, inf)) != hipSuccess) return 16384;
-            worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
-        }
+    for (int g : {team, 1})
+        for (bool pipe : {false, true})
+            for (bool inf : {false, true}) {
+                if (pipe && g < 8) continue;
+                if (hipFuncGetAttributes(&a, block_kernel_of(g, pipe, inf)) != hipSuccess) return 16384;
+                worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+            }
     return (worst + 255) & ~(size_t)255;
 }
 
@@ -578,27 +634,30 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_batch_launch: no grid");
     if (b->gridW != ctx->W || b->gridH != ctx->H) return fail(ctx, RRT_E_ARG, "rrt_batch_launch: grid changed shape");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!b->one_cu_once) b->ms_before = 0.f;
     BatchView v = make_view(b);
     dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
     if (b->use_block) {
         v.lds_chunks = b->blk_lds_chunks;
+        // after a hand-off timed out this one launch continues the batch with one CU per query; the team size the batch was
+        // created with stays and the next launch uses it again
+        const int team = b->one_cu_once ? 1 : b->team;
+        b->one_cu_once = false;
         // a two-deep pipeline of super-blocks (one more workgroup per team, which only commits) for teams of 8 and more
-        bool pipe = b->team >= 8 && !(b->flags & RRT_FLAG_NOPIPE) && b->team_qpad * (b->team + 1) <= ctx->num_cu;
-        if (const char *e = getenv("RRT_PIPE")) pipe = pipe && atoi(e) != 0;
-        if (const char *e = getenv("RRT_PIPE_INFORMED"))  // experiments: Informed queries on the unpipelined team
-            if (atoi(e) == 0)
-                for (const auto &d : b->h_desc)
-                    if (d.status == ST_RUNNING && d.alg == 2) pipe = false;
+        bool pipe = team >= 8 && !(b->flags & RRT_FLAG_NOPIPE) && b->team_qpad * (team + 1) <= ctx->num_cu;
+#ifdef RRT_STAMPS
+        if (const char *e = getenv("RRT_PIPE")) pipe = pipe && atoi(e) != 0;  // diagnostic build only
+#endif
         b->pipe = pipe;
         bool inf = false;  // any Informed query in this launch?
         for (const auto &d : b->h_desc)
             if (d.status == ST_RUNNING && d.alg == 2) inf = true;
-        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(b->team, pipe, inf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
+        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(team, pipe, inf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
-        if (b->team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
+        if (team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
-        const dim3 tg(b->team > 1 ? (unsigned)(b->team_qpad * (b->team + (pipe ? 1 : 0))) : (unsigned)b->Q);
-        hipLaunchKernelGGL(block_kernel_fn_of(b->team, pipe, inf), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        const dim3 tg(team > 1 ? (unsigned)(b->team_qpad * (team + (pipe ? 1 : 0))) : (unsigned)b->Q);
+        hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;
@@ -633,8 +692,11 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
             team_fail = true;
         }
     if (team_fail && b->team > 1) {
-        b->team = 1;
+        float ms0 = 0.f;
+        (void)hipEventElapsedTime(&ms0, b->ev0, b->ev1);  // the launch that timed out counts in rrt_batch_elapsed_ms
         b->team_fallbacks += 1;
+        b->one_cu_once = true;
+        b->ms_before += ms0;
         HIPCHK(ctx, hipMemcpyAsync(b->d_desc, b->h_desc.data(), (size_t)b->Q * sizeof(QDesc), hipMemcpyHostToDevice, ctx->stream));
         int rc = rrt_batch_launch(b);
         if (rc != RRT_OK) return rc;
@@ -661,6 +723,7 @@ extern "C" int rrt_batch_elapsed_ms(rrt_batch *b, float *ms) {
     if (!b || !ms) return fail(nullptr, RRT_E_ARG, "rrt_batch_elapsed_ms: NULL");
     if (!b->timed) return fail(b->ctx, RRT_E_ARG, "rrt_batch_elapsed_ms: nothing launched");
     HIPCHK(b->ctx, hipEventElapsedTime(ms, b->ev0, b->ev1));
+    *ms += b->ms_before;
     return RRT_OK;
 }
 
@@ -730,6 +793,186 @@ extern "C" int rrt_batch_result_block(rrt_batch *b, void **dev_ptr, int64_t *byt
     if (!b || !dev_ptr || !bytes) return fail(nullptr, RRT_E_ARG, "rrt_batch_result_block: NULL");
     *dev_ptr = b->d_slab;
     *bytes = (int64_t)b->slab_bytes;
+    return RRT_OK;
+}
+
+
+// ---- multi-GPU: one process per GPU, query q on rank q mod world, results all-gathered over RCCL ----
+// librccl is opened on first use, so a single-GPU process never loads it.
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load(rrt_ctx *ctx) {
+    if (g_rccl.handle) return RRT_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(ctx, RRT_E_COMM, "cannot open librccl.so.1: %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.AllReduce || !a.GetErrorString) {
+        dlclose(h);
+        return fail(ctx, RRT_E_COMM, "librccl.so.1 lacks an expected symbol");
+    }
+    g_rccl = a;
+    return RRT_OK;
+}
+
+#define RCCLCHK(ctx, call)                                                                                   \
+    do {                                                                                                     \
+        ncclResult_t r_ = (call);                                                                            \
+        if (r_ != ncclSuccess) return fail(ctx, RRT_E_COMM, "%s: %s", #call, g_rccl.GetErrorString(r_));     \
+    } while (0)
+
+// {status, j, vgoal, found} of every query into the tail of the slab, so that a gathered slab is self-describing
+__global__ void slab_meta_kernel(const QDesc *desc, int Q, int32_t *meta) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < Q) {
+        meta[4 * q + 0] = desc[q].status;
+        meta[4 * q + 1] = desc[q].j;
+        meta[4 * q + 2] = desc[q].vgoal;
+        meta[4 * q + 3] = desc[q].found;
+    }
+}
+}  // namespace
+
+extern "C" int rrt_comm_unique_id(uint8_t id[RRT_COMM_ID_BYTES]) {
+    if (!id) return fail(nullptr, RRT_E_ARG, "rrt_comm_unique_id: NULL");
+    static_assert(RRT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    int rc = rccl_load(nullptr);
+    if (rc != RRT_OK) return rc;
+    ncclUniqueId u;
+    RCCLCHK(nullptr, g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return RRT_OK;
+}
+
+extern "C" int rrt_comm_init(rrt_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[RRT_COMM_ID_BYTES]) {
+    if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return fail(ctx, RRT_E_ARG, "rrt_comm_init: bad argument");
+    if (ctx->comm) return fail(ctx, RRT_E_ARG, "rrt_comm_init: the context already has a communicator");
+    int rc = rccl_load(ctx);
+    if (rc != RRT_OK) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    RCCLCHK(ctx, g_rccl.CommInitRank(&ctx->comm, world, u, rank));
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return RRT_OK;
+}
+
+extern "C" int rrt_comm_destroy(rrt_ctx *ctx) {
+    if (!ctx) return RRT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->comm) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    if (ctx->gather_buf) (void)hipFree(ctx->gather_buf);
+    if (ctx->d_red) (void)hipFree(ctx->d_red);
+    ctx->gather_buf = nullptr;
+    ctx->d_red = nullptr;
+    ctx->gather_bytes = 0;
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
+    return RRT_OK;
+}
+
+extern "C" int rrt_comm_allreduce_f64(rrt_ctx *ctx, double *vals, int32_t count, int32_t op) {
+    if (!ctx || !vals || count < 1 || count > 64 || op < 0 || op > 2) return fail(ctx, RRT_E_ARG, "rrt_comm_allreduce_f64: bad argument");
+    if (!ctx->comm) return fail(ctx, RRT_E_COMM, "rrt_comm_allreduce_f64: call rrt_comm_init first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_red) HIPCHK(ctx, hipMalloc((void **)&ctx->d_red, 64 * sizeof(double)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_red, vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+    RCCLCHK(ctx, g_rccl.AllReduce(ctx->d_red, ctx->d_red, (size_t)count, ncclDouble, ops[op], ctx->comm, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(vals, ctx->d_red, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RRT_OK;
+}
+
+extern "C" int rrt_ctx_sync(rrt_ctx *ctx) {
+    if (!ctx) return fail(nullptr, RRT_E_ARG, "rrt_ctx_sync: NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    return RRT_OK;
+}
+
+extern "C" int rrt_gather(rrt_batch *b, void **gathered_dev, int64_t *bytes_per_rank) {
+    if (!b) return fail(nullptr, RRT_E_ARG, "rrt_gather: NULL");
+    rrt_ctx *ctx = b->ctx;
+    if (!ctx->comm) return fail(ctx, RRT_E_COMM, "rrt_gather: call rrt_comm_init first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t need = b->slab_bytes * (size_t)ctx->comm_world;
+    if (ctx->gather_bytes != need) {
+        // every rank must bring a slab of the same size (same Q and capacity): checked once per buffer size
+        double mm[2] = {(double)b->slab_bytes, -(double)b->slab_bytes};
+        int rc = rrt_comm_allreduce_f64(ctx, mm, 2, 1);
+        if (rc != RRT_OK) return rc;
+        if (mm[0] != -mm[1]) return fail(ctx, RRT_E_COMM, "rrt_gather: ranks hold result slabs of different sizes (%.0f .. %.0f bytes)", -mm[1], mm[0]);
+        if (ctx->gather_buf) HIPCHK(ctx, hipFree(ctx->gather_buf));
+        ctx->gather_buf = nullptr;
+        ctx->gather_bytes = 0;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->gather_buf, need));
+        ctx->gather_bytes = need;
+    }
+    int32_t *meta = reinterpret_cast<int32_t *>(b->d_slab + b->slab_bytes - (size_t)b->Q * 4 * sizeof(int32_t));
+    hipLaunchKernelGGL(slab_meta_kernel, dim3((unsigned)((b->Q + 63) / 64)), dim3(64), 0, ctx->stream, b->d_desc, b->Q, meta);
+    HIPCHK(ctx, hipGetLastError());
+    RCCLCHK(ctx, g_rccl.AllGather(b->d_slab, ctx->gather_buf, b->slab_bytes, ncclUint8, ctx->comm, ctx->stream));
+    if (gathered_dev) *gathered_dev = ctx->gather_buf;
+    if (bytes_per_rank) *bytes_per_rank = (int64_t)b->slab_bytes;
+    return RRT_OK;
+}
+
+extern "C" int rrt_gather_fetch(rrt_batch *b, int32_t rank, int32_t q, rrt_result *out) {
+    if (!b || !out) return fail(nullptr, RRT_E_ARG, "rrt_gather_fetch: NULL");
+    rrt_ctx *ctx = b->ctx;
+    if (!ctx->gather_buf || ctx->gather_bytes != b->slab_bytes * (size_t)ctx->comm_world)
+        return fail(ctx, RRT_E_COMM, "rrt_gather_fetch: call rrt_gather on this batch first");
+    if (rank < 0 || rank >= ctx->comm_world || q < 0 || q >= b->Q) return fail(ctx, RRT_E_ARG, "rrt_gather_fetch: rank %d, query %d", rank, q);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const unsigned char *slab = ctx->gather_buf + (size_t)rank * b->slab_bytes;
+    const size_t Q = (size_t)b->Q, S = (size_t)b->node_stride;
+    int32_t meta[4];
+    HIPCHK(ctx, hipMemcpyAsync(meta, slab + Q * S * 16 + (size_t)q * 16, sizeof meta, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    out->status = meta[0];
+    out->j = meta[1];
+    out->vgoal = meta[2];
+    out->found = meta[3];
+    const int live = meta[1] + (meta[3] ? 1 : 0);
+    if (live < 0 || (size_t)live > S) return fail(ctx, RRT_E_COMM, "rrt_gather_fetch: rank %d query %d carries %d rows", rank, q, live);
+    if (out->pts) {
+        std::vector<uint32_t> tmp((size_t)live);
+        HIPCHK(ctx, hipMemcpyAsync(tmp.data(), slab + Q * S * 8 + ((size_t)q * S) * 4, (size_t)live * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < live; ++k) {
+            out->pts[2 * k] = (int32_t)(tmp[(size_t)k] & 0xffffu);
+            out->pts[2 * k + 1] = (int32_t)(tmp[(size_t)k] >> 16);
+        }
+    }
+    if (out->vcost) HIPCHK(ctx, hipMemcpyAsync(out->vcost, slab + ((size_t)q * S) * 8, (size_t)live * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out->parent)
+        HIPCHK(ctx, hipMemcpyAsync(out->parent, slab + Q * S * 12 + ((size_t)q * S) * 4, (size_t)live * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RRT_OK;
 }
 
@@ -810,11 +1053,12 @@ extern "C" int rrt_prim_collisionfree(rrt_ctx *ctx, const int32_t *ab, int32_t m
             ab[4 * k + 1] >= ctx->H || ab[4 * k + 3] < 0 || ab[4 * k + 3] >= ctx->H)
             return fail(ctx, RRT_E_ARG, "rrt_prim_collisionfree: segment %d outside the grid", k);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevTmp tmp;
     int32_t *d_ab = nullptr, *d_cells = nullptr;
     uint8_t *d_free = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_ab, (size_t)m * 4 * sizeof(int32_t)));
-    HIPCHK(ctx, hipMalloc((void **)&d_cells, (size_t)m * sizeof(int32_t)));
-    HIPCHK(ctx, hipMalloc((void **)&d_free, (size_t)m));
+    HIPCHK(ctx, tmp.alloc(&d_ab, (size_t)m * 4 * sizeof(int32_t)));
+    HIPCHK(ctx, tmp.alloc(&d_cells, (size_t)m * sizeof(int32_t)));
+    HIPCHK(ctx, tmp.alloc(&d_free, (size_t)m));
     HIPCHK(ctx, hipMemcpyAsync(d_ab, ab, (size_t)m * 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     const int waves_per_block = 4;
     hipLaunchKernelGGL(prim_los_kernel, dim3((unsigned)((m + waves_per_block - 1) / waves_per_block)), dim3(64 * waves_per_block), 0,
@@ -822,9 +1066,6 @@ extern "C" int rrt_prim_collisionfree(rrt_ctx *ctx, const int32_t *ab, int32_t m
     HIPCHK(ctx, hipMemcpyAsync(out_free, d_free, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     if (out_cells) HIPCHK(ctx, hipMemcpyAsync(out_cells, d_cells, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipFree(d_ab));
-    HIPCHK(ctx, hipFree(d_cells));
-    HIPCHK(ctx, hipFree(d_free));
     return RRT_OK;
 }
 
@@ -834,6 +1075,7 @@ extern "C" int rrt_prim_nearest_within(rrt_ctx *ctx, const int32_t *pts, int32_t
     if ((long long)j > 64LL * CHUNK) return fail(ctx, RRT_E_UNSUPPORTED, "rrt_prim_nearest_within: j too large");
     if (m == 0) return RRT_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevTmp tmp;
     std::vector<uint32_t> hp((size_t)((j + 3) & ~3), 0), hq((size_t)m);
     for (int k = 0; k < j; ++k) {
         if (pts[2 * k] < 0 || pts[2 * k] >= 2048 || pts[2 * k + 1] < 0 || pts[2 * k + 1] >= 2048)
@@ -849,13 +1091,13 @@ extern "C" int rrt_prim_nearest_within(rrt_ctx *ctx, const int32_t *pts, int32_t
     int32_t *d_nn = nullptr, *d_cnt = nullptr;
     unsigned long long *d_sum = nullptr;
     uint2 *d_spill = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_sum, (size_t)m * sizeof(unsigned long long)));
+    HIPCHK(ctx, tmp.alloc(&d_sum, (size_t)m * sizeof(unsigned long long)));
     const int spill_stride = ((j + CHUNK - 1) / CHUNK) * CHUNK;
-    HIPCHK(ctx, hipMalloc((void **)&d_spill, (size_t)m * (size_t)spill_stride * sizeof(uint2)));
-    HIPCHK(ctx, hipMalloc((void **)&d_p, hp.size() * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMalloc((void **)&d_q, hq.size() * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMalloc((void **)&d_nn, (size_t)m * sizeof(int32_t)));
-    HIPCHK(ctx, hipMalloc((void **)&d_cnt, (size_t)m * sizeof(int32_t)));
+    HIPCHK(ctx, tmp.alloc(&d_spill, (size_t)m * (size_t)spill_stride * sizeof(uint2)));
+    HIPCHK(ctx, tmp.alloc(&d_p, hp.size() * sizeof(uint32_t)));
+    HIPCHK(ctx, tmp.alloc(&d_q, hq.size() * sizeof(uint32_t)));
+    HIPCHK(ctx, tmp.alloc(&d_nn, (size_t)m * sizeof(int32_t)));
+    HIPCHK(ctx, tmp.alloc(&d_cnt, (size_t)m * sizeof(int32_t)));
     HIPCHK(ctx, hipMemcpyAsync(d_p, hp.data(), hp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_q, hq.data(), hq.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     const int64_t cap = 1 << 24;
@@ -867,12 +1109,6 @@ extern "C" int rrt_prim_nearest_within(rrt_ctx *ctx, const int32_t *pts, int32_t
     if (out_within_idxsum)
         HIPCHK(ctx, hipMemcpyAsync(out_within_idxsum, d_sum, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipFree(d_p));
-    HIPCHK(ctx, hipFree(d_q));
-    HIPCHK(ctx, hipFree(d_nn));
-    HIPCHK(ctx, hipFree(d_cnt));
-    HIPCHK(ctx, hipFree(d_sum));
-    HIPCHK(ctx, hipFree(d_spill));
     return RRT_OK;
 }
 
@@ -880,12 +1116,12 @@ extern "C" int rrt_prim_sqrt_u32(rrt_ctx *ctx, uint32_t lo, uint32_t count, doub
     if (!ctx || !out) return fail(ctx, RRT_E_ARG, "rrt_prim_sqrt_u32: NULL");
     if (count == 0) return RRT_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevTmp tmp;
     double *d = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d, (size_t)count * sizeof(double)));
+    HIPCHK(ctx, tmp.alloc(&d, (size_t)count * sizeof(double)));
     hipLaunchKernelGGL(prim_sqrt_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, lo, count, d);
     HIPCHK(ctx, hipMemcpyAsync(out, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipFree(d));
     return RRT_OK;
 }
 
@@ -894,12 +1130,12 @@ extern "C" int rrt_prim_sqrt_u24(rrt_ctx *ctx, uint32_t lo, uint32_t count, doub
     if ((unsigned long long)lo + count > (1ull << 24)) return fail(ctx, RRT_E_ARG, "rrt_prim_sqrt_u24: radicand >= 2^24");
     if (count == 0) return RRT_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevTmp tmp;
     double *d = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d, (size_t)count * sizeof(double)));
+    HIPCHK(ctx, tmp.alloc(&d, (size_t)count * sizeof(double)));
     hipLaunchKernelGGL(prim_sqrt_u24_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, lo, count, d);
     HIPCHK(ctx, hipMemcpyAsync(out, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipFree(d));
     return RRT_OK;
 }
 
@@ -907,14 +1143,13 @@ extern "C" int rrt_prim_sqrt_f64(rrt_ctx *ctx, const double *in, uint32_t count,
     if (!ctx || !in || !out) return fail(ctx, RRT_E_ARG, "rrt_prim_sqrt_f64: NULL");
     if (count == 0) return RRT_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevTmp tmp;
     double *d_in = nullptr, *d_out = nullptr;
-    HIPCHK(ctx, hipMalloc((void **)&d_in, (size_t)count * sizeof(double)));
-    HIPCHK(ctx, hipMalloc((void **)&d_out, (size_t)count * sizeof(double)));
+    HIPCHK(ctx, tmp.alloc(&d_in, (size_t)count * sizeof(double)));
+    HIPCHK(ctx, tmp.alloc(&d_out, (size_t)count * sizeof(double)));
     HIPCHK(ctx, hipMemcpyAsync(d_in, in, (size_t)count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(prim_sqrt_f64_kernel, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, d_in, count, d_out);
     HIPCHK(ctx, hipMemcpyAsync(out, d_out, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipFree(d_in));
-    HIPCHK(ctx, hipFree(d_out));
     return RRT_OK;
 }

@@ -1,12 +1,16 @@
-"""Many independent queries: sharding across GPUs and the result gather.
+"""Many independent queries: sharding across the GPUs of one node and the result gather.
 
 Queries are independent (own tree, own RNG stream, shared read-only grid), so the path shards
 with no data-path collective: query q runs on rank q % world_size.  The one
-exchange step is the gather of the fixed-size result slabs at the end of a batch, done with
-torch.distributed (backend "nccl" == RCCL over xGMI on the GPU node, "gloo" in the CPU tests).
-torch is used here only as plumbing for the process group and the collective; the planner
-package itself does not import it.
+exchange step is the all-gather of the fixed-size result slabs at the end of a batch; it lives in
+the C ABI (``rrt_comm_init`` / ``rrt_gather``: ncclAllGather on the context's stream, RCCL over
+xGMI).  This module holds the host side around it: the shard map, the hand-over of the
+communicator id between the ranks of a node, and the slab layout.  No torch: a launcher such as
+``python -m torch.distributed.run`` only starts the rank processes and sets RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_PORT.
 """
+import os
+import time
 from typing import List
 
 
@@ -26,36 +30,89 @@ def local_slot(q: int, world_size: int) -> int:
     return q // world_size
 
 
-class DeviceBlock:
-    """Zero-copy view of a device allocation for torch (``__cuda_array_interface__``)."""
+# ---------------------------------------------------------------------------------- communicator id hand-over
+def _launcher_key() -> str:
+    """A name all ranks of one launch on this node agree on and no other launch shares: the launcher's pid and start
+    time (every rank is a child of the same launcher process) plus the rendezvous port."""
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time in clock ticks since boot
+    except (OSError, IndexError):
+        pass
+    return f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}"
 
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+def exchange_unique_id(rank: int, world_size: int, make_id, path: str = None, timeout: float = 120.0) -> bytes:
+    """Rank 0 calls `make_id()` (-> 128 bytes, ``_ffi.comm_unique_id``) and publishes the result; the other ranks of the
+    node wait for it.  Single node, so a file on local tmpfs is the side channel: written under a temporary name and
+    renamed, so a reader sees all of it or nothing.  Rank 0 removes the file in `release_unique_id` once the
+    communicator exists (ncclCommInitRank returns only after every rank has joined, i.e. has read the file)."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank {rank} of {world_size}")
+    if path is None:
+        base = os.environ.get("RRT_COMM_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+        path = os.path.join(base, f"rrt_comm_{_launcher_key()}.id")
+    if rank == 0:
+        uid = bytes(make_id())
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) > 0:
+                return uid
+        except OSError:
+            pass
+        if time.monotonic() > deadline:
+            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s")
+        time.sleep(0.01)
 
 
-def gather_result_blocks(local_block, group=None):
-    """All-gather equally sized uint8 result slabs (1-D tensors) from every rank.
+def release_unique_id(rank: int, path: str = None):
+    if rank != 0:
+        return
+    if path is None:
+        base = os.environ.get("RRT_COMM_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+        path = os.path.join(base, f"rrt_comm_{_launcher_key()}.id")
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
 
-    Returns a (world_size, nbytes) tensor on the same device as `local_block`; row r is rank r's
-    slab.  One collective per batch: with RCCL this is a single ncclAllGather over xGMI."""
-    import torch
-    import torch.distributed as dist
 
-    ws = dist.get_world_size(group)
-    out = torch.empty((ws, local_block.numel()), dtype=local_block.dtype, device=local_block.device)
-    dist.all_gather_into_tensor(out.view(-1), local_block.contiguous(), group=group)
-    return out
+def init_comm(ctx, rank: int, world_size: int, path: str = None):
+    """Create the RCCL communicator of `ctx` (an ``_ffi.Context`` on this rank's GPU): collective over all ranks."""
+    from . import _ffi
+
+    uid = exchange_unique_id(rank, world_size, _ffi.comm_unique_id, path=path)
+    ctx.comm_init(rank, world_size, uid)
+    release_unique_id(rank, path=path)
+
+
+# ---------------------------------------------------------------------------------- slab layout
+def slab_bytes(Q: int, node_stride: int) -> int:
+    return Q * node_stride * 16 + Q * 16
 
 
 def unpack_slab(slab, Q: int, node_stride: int):
-    """Split one rank's slab (uint8 numpy array) into (vcost[Q,stride] f64, nodes[Q,stride] u32,
-    parent[Q,stride] i32) -- the layout of rrt_batch_result_block."""
+    """Split one rank's slab (uint8 numpy array) into (vcost[Q,stride] f64, nodes[Q,stride] u32, parent[Q,stride] i32,
+    meta[Q,4] i32 = {status, j, vgoal, found}) -- the layout of rrt_batch_result_block / rrt_gather."""
     import numpy as np
 
     a = np.asarray(slab, dtype=np.uint8)
+    if a.size != slab_bytes(Q, node_stride):
+        raise ValueError(f"slab of {a.size} bytes does not hold {Q} queries of stride {node_stride}")
     n8 = Q * node_stride * 8
     n4 = Q * node_stride * 4
     vcost = a[:n8].view(np.float64).reshape(Q, node_stride)
     nodes = a[n8:n8 + n4].view(np.uint32).reshape(Q, node_stride)
     parent = a[n8 + n4:n8 + 2 * n4].view(np.int32).reshape(Q, node_stride)
-    return vcost, nodes, parent
+    meta = a[n8 + 2 * n4:].view(np.int32).reshape(Q, 4)
+    return vcost, nodes, parent, meta

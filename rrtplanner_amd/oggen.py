@@ -120,6 +120,14 @@ class DeviceGrids:
         self.ctx = ctx
         self.host = ctx.noise_grids(w, h, frames, np.float32(thresh), dims, [c for c, _, _ in lat], [a for _, a, _ in lat], grads).astype(np.int64)
         self.frames = frames
+        self.generation = ctx.grid_generation()  # the frames live in the context's grid storage: any later upload evicts them
+
+    def valid(self) -> bool:
+        """False once something else (set_grid via planner.set_og + plan, another DeviceGrids) rewrote the context's grid."""
+        return self.ctx.grid_generation() == self.generation
 
     def select(self, k: int):
+        if not self.valid():
+            raise RuntimeError("the device frames of this DeviceGrids are gone: the context's grid was uploaded or regenerated "
+                               "since (set_og + plan, or another DeviceGrids on the same context); generate them again")
         self.ctx.select_frame(k)

@@ -240,10 +240,11 @@ class RRT(object):
 
     def set_og_resident(self, grids, k: int = 0):
         """Like set_og(grids.host[k]) for grids generated on this planner's device (oggen.DeviceGrids): frame k
-        becomes the active grid without an upload."""
+        becomes the active grid without an upload.  Raises RuntimeError when the frames are no longer on the device
+        (a set_og() + plan() or another DeviceGrids on the same context replaced them)."""
         if self._ctx is None or grids.ctx is not self._ctx:
             raise ValueError("grids were generated on a different device context: use oggen.DeviceGrids(planner.device_context(), ...)")
-        grids.select(k)
+        grids.select(k)  # checks the context's grid generation
         self.og = grids.host[k]
         self.free = np.argwhere(self.og == 0)
         self._grid_dirty = False
@@ -349,12 +350,32 @@ class RRT(object):
 
     def _plan(self, alg, xstart, xgoal, **kw):
         bar = tqdm(total=self.n) if self.pbar else None
-        res = self._run(alg, xstart, xgoal, **kw)
-        out = self._materialise(res)
-        if bar is not None:
-            bar.update(self.n)
-            bar.close()
+        try:
+            res = self._run(alg, xstart, xgoal, **kw)
+            out = self._materialise(res)
+            if bar is not None:
+                bar.update(self.n)
+        finally:
+            if bar is not None:
+                bar.close()
         return res, out
+
+    def go2goal(self, vcosts, points, xgoal, j, children, parents):
+        """Connect the goal to the cheapest tree vertex that sees it (reference rrt.py:284-332), on the host arrays the
+        caller passes -- the helper of the reference's public surface; plan() itself does this step on the device.
+        Returns (vgoal, children, parents, points, vcosts) with the arrays grown by one row when a vertex was found, else
+        vgoal = 0 like rrt.py:330-331.  Equal costs are tried in index order (the canonical tie policy)."""
+        costs = np.array([self.cost(vcosts, points, i, xgoal) for i in range(points.shape[0])], dtype=np.float64).reshape(vcosts.shape)
+        for idx in np.argsort(costs, kind="stable"):
+            if self.collisionfree(self.og, points[idx], xgoal):
+                vgoal = j
+                points = np.concatenate((points, xgoal[np.newaxis, :]), axis=0)
+                vcosts = np.concatenate((vcosts, [costs[idx]]), axis=0)
+                points[vgoal], vcosts[vgoal] = xgoal, costs[idx]
+                children[idx].append(vgoal)
+                parents[vgoal] = idx
+                return vgoal, children, parents, points, vcosts
+        return int(np.argmin(np.linalg.norm(points - xgoal))), children, parents, points, vcosts
 
 
 class RRTStandard(RRT):
@@ -394,6 +415,44 @@ class RRTStarInformed(RRT):
         res, out = self._plan(_ffi.ALG_INFORMED, xstart, xgoal, r_rewire=self.r_rewire, r_goal=self.r_goal)
         self._record_ellipses(res)
         return out
+
+    # ---- the sampler's helpers of the reference's public surface (rrt.py:579-651), on the host.  plan() draws the same
+    # numbers in blocks (hostprep.draw_unitball) and applies the ellipse transform on the device.
+    def unitball(self) -> np.ndarray:
+        """One point of the unit disc, two uniform draws from the planner's generator (rrt.py:579-587)."""
+        return hostprep.draw_unitball(self.rand_gen, 1)[0]
+
+    def rotation_to_world_frame(self, xstart, xgoal) -> np.ndarray:
+        return hostprep.rotation_to_world_frame(np.asarray(xstart), np.asarray(xgoal))
+
+    def get_ellipse_xform(self, xstart, xgoal, cmax) -> np.ndarray:
+        """C @ diag(cmax / 2, sqrt(|cmax^2 - |xstart - xgoal|^2|) / 2)   (rrt.py:615-625)"""
+        d = np.asarray(xstart) - np.asarray(xgoal)
+        return np.dot(self.rotation_to_world_frame(xstart, xgoal), np.diag([cmax / 2, np.sqrt(abs(cmax * cmax - np.dot(d.T, d))) / 2]))
+
+    def sample_ellipse(self, xstart, xgoal, c, clamp=True) -> np.ndarray:
+        """A sample of the ellipse with foci xstart / xgoal and path length c, clamped to the grid (rrt.py:589-599)."""
+        x, y = tuple(np.dot(self.get_ellipse_xform(xstart, xgoal, c), self.unitball()) + (np.asarray(xstart) + np.asarray(xgoal)) / 2)
+        if clamp:
+            x = int(max(0, min(self.og.shape[0] - 1, x)))
+            y = int(max(0, min(self.og.shape[1] - 1, y)))
+        return np.array((x, y))
+
+    @staticmethod
+    def least_cost(vcosts, vsoln):
+        """(vertex, cost) of the cheapest solution vertex, the first one among equals (rrt.py:627-633)."""
+        k = int(np.argmin(vcosts[vsoln])) if len(vsoln) > 1 else 0
+        return vsoln[k], vcosts[vsoln[k]]
+
+    @staticmethod
+    def rad2deg(a):
+        return a * 180 / np.pi
+
+    def get_ellipse_for_plt(self, xstart, xgoal, cmax):
+        """(centre, major axis, minor axis, angle in degrees) for matplotlib's Ellipse (rrt.py:639-651)."""
+        CL = self.get_ellipse_xform(xstart, xgoal, cmax)
+        a, b = CL[:, 0], CL[:, 1]
+        return (np.asarray(xgoal) + np.asarray(xstart)) / 2, 2 * np.linalg.norm(a), 2 * np.linalg.norm(b), self.rad2deg(np.arctan2(a[1], a[0]))
 
     def _record_ellipses(self, res):
         """self.ellipses[j] = get_ellipse_for_plt(...) of every ellipse iteration (rrt.py:701); a

@@ -1,6 +1,7 @@
-"""CPU, world_size 2 over gloo: the N > 1 path of bench.py -- round-robin sharding of independent queries,
-one all-gather of fixed-size result slabs, max-over-ranks timing.  The expansion itself is stood in by the
-CPU oracle here (tests only); on the GPU node the same code runs over RCCL."""
+"""CPU, world_size 2: the N > 1 path of bench.py -- round-robin sharding of independent queries, the hand-over of the
+communicator id between the ranks, one all-gather of fixed-size self-describing result slabs, max-over-ranks timing.
+Here gloo's all_gather stands in for the ncclAllGather of rrt_gather (C ABI, needs GPUs) and the CPU oracle for the
+expansion (tests only); the shard map, the slab layout and the id hand-over are the product's (rrtplanner_amd/multi.py)."""
 import os
 import socket
 
@@ -36,6 +37,7 @@ def _worker(rank, world, port, total, n, out_dir):
     stride = ((n + 1 + 4095) // 4096) * 4096
     Q = len(mine)
     vcost = np.zeros((Q, stride)); nodes = np.zeros((Q, stride), dtype=np.uint32); parent = np.zeros((Q, stride), dtype=np.int32)
+    meta = np.zeros((Q, 4), dtype=np.int32)
     for slot, g in enumerate(mine):
         xs, xg = pairs[g]
         s = hostprep.draw_free_samples(np.random.default_rng(g), free, n)
@@ -44,8 +46,16 @@ def _worker(rank, world, port, total, n, out_dir):
         vcost[slot, :live] = r.vcost[:live]
         nodes[slot, :live] = r.pts[:live, 0].astype(np.uint32) | (r.pts[:live, 1].astype(np.uint32) << 16)
         parent[slot, :live] = r.parent[:live]
-    slab = np.concatenate([vcost.view(np.uint8).ravel(), nodes.view(np.uint8).ravel(), parent.view(np.uint8).ravel()])
-    blocks = multi.gather_result_blocks(torch.from_numpy(slab))
+        meta[slot] = (st, r.j, r.vgoal, r.found)
+    slab = np.concatenate([vcost.view(np.uint8).ravel(), nodes.view(np.uint8).ravel(), parent.view(np.uint8).ravel(),
+                           meta.view(np.uint8).ravel()])
+    assert slab.size == multi.slab_bytes(Q, stride)
+    # the id hand-over of multi.init_comm (the id itself is only meaningful to RCCL)
+    uid = multi.exchange_unique_id(rank, world, lambda: bytes(range(128)), path=os.path.join(out_dir, "comm.id"))
+    assert uid == bytes(range(128))
+    local = torch.from_numpy(slab)
+    blocks = torch.empty((world, local.numel()), dtype=torch.uint8)
+    dist.all_gather_into_tensor(blocks.view(-1), local)
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -64,18 +74,45 @@ def test_two_rank_shard_and_gather(tmp_path):
     assert np.load(tmp_path / "tmax.npy")[0] == pytest.approx(0.2)
     stride = ((n + 1 + 4095) // 4096) * 4096
     Q = total // world
-    assert blocks.shape == (world, Q * stride * 16)
+    assert blocks.shape == (world, multi.slab_bytes(Q, stride))
     og = perlin_occupancygrid(96, 96, seed=2)
     og8 = oracle.og_u8(og)
     free = np.argwhere(og == 0)
     sg = np.random.default_rng(7)
     pairs = [random_connected_pair(og, sg) for _ in range(total)]
     for g in range(total):
-        v, nd, pa = multi.unpack_slab(blocks[multi.owner_of(g, world)], Q, stride)
+        v, nd, pa, meta = multi.unpack_slab(blocks[multi.owner_of(g, world)], Q, stride)
         slot = multi.local_slot(g, world)
         xs, xg = pairs[g]
         s = hostprep.draw_free_samples(np.random.default_rng(g), free, n)
         st, r = oracle.plan(og8, n, 1, xs, xg, s, r2_rewire=hostprep.radius_threshold(16), logs=False)
         live = r.j + (1 if r.found else 0)
+        assert meta[slot].tolist() == [st, r.j, r.vgoal, r.found]
         assert np.array_equal(nd[slot, :live] & 0xffff, r.pts[:live, 0]) and np.array_equal(nd[slot, :live] >> 16, r.pts[:live, 1])
         assert np.array_equal(pa[slot, :live], r.parent[:live]) and np.array_equal(v[slot, :live], r.vcost[:live])
+
+
+def _id_worker(rank, world, path, q):
+    q.put((rank, multi.exchange_unique_id(rank, world, lambda: os.urandom(128), path=path, timeout=30.0)))
+
+
+def test_unique_id_hand_over_between_three_ranks(tmp_path):
+    """Rank 0 publishes, the others poll (started first, so they really wait); all see the same 128 bytes; the launcher
+    key is the same in every child of one parent."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    path = str(tmp_path / "x.id")
+    ps = [ctx.Process(target=_id_worker, args=(r, 3, path, q)) for r in (2, 1, 0)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert len(got[0]) == 128 and got[0] == got[1] == got[2]
+    multi.release_unique_id(0, path=path)
+    assert not os.path.exists(path)
+    assert multi._launcher_key().split("_")[0] == str(os.getppid())
+    with pytest.raises(TimeoutError):
+        multi.exchange_unique_id(1, 2, None, path=str(tmp_path / "never.id"), timeout=0.2)

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 P = orchelp.golden("primitives.npz").z
 GA = orchelp.golden("plans_A.npz")
 GS = orchelp.golden("special_A.npz")
+GBIG = orchelp.golden("plans_big_A.npz")
 
 
 # ------------------------------------------------------------------------------- primitives
@@ -129,6 +130,22 @@ def test_plan_special_cases(meta):
     _run_case(GS, meta)
 
 
+@pytest.mark.parametrize("meta", GBIG.manifest, ids=[m["id"] for m in GBIG.manifest])
+def test_plan_bench_scale_and_grid_dtypes(meta):
+    """The device against the REAL reference at bench scale: query 0 of BASELINE config 4 on the bench's own 1024x1024 grid
+    (n = 20000, r_rewire = 64), Informed RRT* on 400x400 (n = 6000), and the reference's 8 occupancy-grid dtypes
+    (tests/test_rrt.py:8-17; a fractional cell value is an obstacle like any non-zero)."""
+    og = GBIG.grid(meta["grid"]).astype(np.int64)
+    if "og_dtype" in meta:
+        dt = {"int": int, "float": float}.get(meta["og_dtype"]) or getattr(np, meta["og_dtype"])
+        og = og.astype(dt)
+        if meta["fractional"]:
+            og[30, 30] = 0.25
+    p = orchelp.make_planner(amd, meta, og)
+    T, gv = p.plan(np.array(meta["xstart"]), np.array(meta["xgoal"]))
+    orchelp.check_plan_against_golden(GBIG, meta, p, T, gv)
+
+
 @pytest.mark.parametrize("tag", ["std", "star", "inf"])
 def test_replan_chain_rng_continues_and_set_og(tag):
     chain = sorted([m for m in GS.manifest if m.get("chain") == f"replan__{tag}"], key=lambda m: m["step"])
@@ -211,6 +228,18 @@ def test_device_vs_oracle_informed_1024_n25000(gpu_ctx, kernel):
     xs, xg = random_connected_pair(og, np.random.default_rng(7))
     res, ro = _oracle_vs_device(gpu_ctx, og8, 2, 25000, 0, xs, xg, 64, 12, kernel=kernel)
     assert res.i_switch < 25000  # the ellipse phase was reached
+
+
+@pytest.mark.parametrize("kernel", ["team", "block"])
+def test_device_vs_oracle_informed_config3_full_size(gpu_ctx, kernel):
+    """BASELINE config 3 at its full size: Informed RRT*, 1024x1024, n = 50000, r_rewire = 64, r_goal = 12 (the pipelined team's
+    RESTART / void blocks and every ellipse move of the bench run), every array and per-iteration log against the oracle."""
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    xs, xg = random_connected_pair(og, np.random.default_rng(7))
+    res, ro = _oracle_vs_device(gpu_ctx, og8, 2, 50000, 0, xs, xg, 64, 12, kernel=kernel)
+    assert res.i_switch < 50000
 
 
 @pytest.mark.parametrize("kernel", KERNELS_NOFAULT)
@@ -311,6 +340,134 @@ def test_batch_of_queries_matches_single_queries(gpu_ctx):
     b.close()
 
 
+def _bench_config4_queries(og, free, Q, n, first=0, stride=1):
+    """bench.py's config-4 queries first, first + stride, ...: start/goal from default_rng(7), planner seed = query index."""
+    sg = np.random.default_rng(7)
+    pairs = [random_connected_pair(og, sg) for _ in range(first + stride * Q)]
+    out = []
+    for k in range(Q):
+        g = first + stride * k
+        xs, xg = pairs[g]
+        samples = hostprep.draw_free_samples(np.random.default_rng(g), free, n)
+        out.append((xs, xg, samples))
+    return out
+
+
+def test_config4_share_of_one_gpu_equals_the_oracle(gpu_ctx):
+    """BASELINE configs[3]'s per-GPU share exactly as bench.py's `batched` leg runs it: 64 independent RRT* queries, n = 20000,
+    r_rewire = 64, the 1024x1024 bench grid, default teams (4 CUs per query, all 256 CUs busy, 64 teams contending for L2).
+    Every query's nodes, parents and costs must equal the oracle's, no hand-off may time out, and a second launch after
+    rearm must reproduce them."""
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    Q, n = 64, 20000
+    r2 = hostprep.radius_threshold(64)
+    qs = _bench_config4_queries(og, free, Q, n)
+    b = _ffi.Batch(gpu_ctx, Q, n)
+    keep = []
+    for q, (xs, xg, samples) in enumerate(qs):
+        qu, k = _ffi.make_query(1, n, xs, xg, samples, r2_rewire=r2)
+        keep.append(k)
+        b.set_query(q, qu)
+    refs = [oracle.plan(og8, n, 1, xs, xg, samples, r2_rewire=r2, logs=False) for xs, xg, samples in qs]
+    for rep in range(2):
+        b.launch()
+        b.sync()
+        assert b.team() == (4, 0)
+        for q in range(Q):
+            res = b.get_result(q)
+            st, ro = refs[q]
+            live = ro.j + (1 if ro.found else 0)
+            assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal and res.found == ro.found, q
+            assert np.array_equal(res.pts[:live], ro.pts[:live]), q
+            assert np.array_equal(res.parent[:live], ro.parent[:live]), q
+            assert np.array_equal(res.vcost[:live], ro.vcost[:live]), q
+            assert res.sum_j == ro.sum_j and res.sum_cells_nn == ro.sum_cells_nn and res.sum_near == ro.sum_near, q
+        b.rearm()
+    b.close()
+    # query 0 of this batch is also pinned to the real reference: tests/golden/plans_big_A.npz (bench1024__star_r64__s0__n20000)
+    m = GBIG.by_id["bench1024__star_r64__s0__n20000"]
+    assert m["xstart"] == [int(v) for v in qs[0][0]] and m["xgoal"] == [int(v) for v in qs[0][1]]
+    live = refs[0][1].j + 1
+    assert np.array_equal(GBIG.arr(m["id"], "parent")[:live], refs[0][1].parent[:live])
+
+
+def test_plan_batch_one_shot(gpu_ctx):
+    """rrt_plan_batch (the one-call form of the batch API): 6 mixed RRTStandard / RRTStar queries of different n."""
+    og = perlin_occupancygrid(512, 512, seed=2)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    sg = np.random.default_rng(3)
+    ns = [2500, 4000, 1, 3999, 64, 4000]
+    queries, keep, refs = [], [], []
+    for q, n in enumerate(ns):
+        xs, xg = random_connected_pair(og, sg)
+        samples = hostprep.draw_free_samples(np.random.default_rng(50 + q), free, n)
+        alg = q % 2
+        r2 = hostprep.radius_threshold(40) if alg else 0
+        qu, k = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2)
+        queries.append(qu)
+        keep.append(k)
+        refs.append(oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=r2, logs=False))
+    rc, res = gpu_ctx.plan_batch(queries, ns)
+    assert rc == next((st for st, _ in refs if st != 0), 0)
+    for q, (st, ro) in enumerate(refs):
+        live = ro.j + (1 if ro.found else 0)
+        assert res[q].status == st and res[q].j == ro.j and res[q].vgoal == ro.vgoal and res[q].rows == ro.rows
+        assert np.array_equal(res[q].pts[:live], ro.pts[:live])
+        assert np.array_equal(res[q].parent[:live], ro.parent[:live])
+        assert np.array_equal(res[q].vcost[:live], ro.vcost[:live])
+
+
+def test_gather_single_rank_self_test():
+    """rrt_comm_init / rrt_gather / rrt_gather_fetch / rrt_comm_allreduce_f64 on a communicator of one rank (all a one-GPU box
+    can hold): the gathered slab is the batch's own, self-describing ({status, j, vgoal, found} per query), and fetch returns
+    the oracle's trees.  The N > 1 shard / layout / id hand-over logic is covered on CPU (tests/test_dist_gloo.py)."""
+    from rrtplanner_amd import multi
+
+    ctx = _ffi.Context(0)
+    og = perlin_occupancygrid(256, 256, seed=4)
+    og8 = oracle.og_u8(og)
+    ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    multi.init_comm(ctx, 0, 1)
+    assert ctx.allreduce([1.5, -2.0], "max").tolist() == [1.5, -2.0] and ctx.allreduce([3.0]).tolist() == [3.0]
+    ctx.barrier()
+    Q, n = 5, 3000
+    b = _ffi.Batch(ctx, Q, n)
+    sg = np.random.default_rng(9)
+    refs, keep = [], []
+    for q in range(Q):
+        xs, xg = random_connected_pair(og, sg)
+        samples = hostprep.draw_free_samples(np.random.default_rng(q), free, n)
+        qu, k = _ffi.make_query(1, n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(30))
+        keep.append(k)
+        b.set_query(q, qu)
+        refs.append(oracle.plan(og8, n, 1, xs, xg, samples, r2_rewire=hostprep.radius_threshold(30), logs=False))
+    b.launch()
+    b.sync()
+    ptr, nbytes = b.gather()
+    assert ptr and nbytes == b.result_block()[1] and nbytes == multi.slab_bytes(Q, ((n + 1 + 4095) // 4096) * 4096)
+    for q in range(Q):
+        st, ro = refs[q]
+        res = b.gather_fetch(0, q)
+        live = ro.j + (1 if ro.found else 0)
+        assert (res.status, res.j, res.vgoal, res.found) == (st, ro.j, ro.vgoal, ro.found)
+        assert np.array_equal(res.pts[:live], ro.pts[:live]) and np.array_equal(res.parent[:live], ro.parent[:live])
+        assert np.array_equal(res.vcost[:live], ro.vcost[:live])
+    with pytest.raises(_ffi.RRTError):
+        b.gather_fetch(1, 0)  # no such rank
+    b.close()
+    ctx.comm_destroy()
+    with pytest.raises(_ffi.RRTError) as e:
+        ctx.allreduce([1.0])
+    assert e.value.code == _ffi.RRT_E_COMM
+    ctx.close()
+
+
 def test_pipelined_informed_batch_has_no_timeouts(gpu_ctx):
     """Informed queries on pipelined teams (blocks in flight are voided when a commit moves the ellipse): the staged API with the
     host's unit-ball hand-over, no hand-off may time out, trees equal the oracle's."""
@@ -381,17 +538,20 @@ def test_team_that_loses_a_member_finishes_on_one_cu_per_query(gpu_ctx):
         keep.append(k)
         b.set_query(q, qu)
         refs.append(oracle.plan(og8, n, 1, xs, xg, samples, r2_rewire=hostprep.radius_threshold(40)))
-    b.launch()
-    b.sync()
-    assert b.team() == (1, 1)
-    for q in range(Q):
-        res = b.get_result(q)
-        st, ro = refs[q]
-        live = ro.j + (1 if ro.found else 0)
-        assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal
-        assert np.array_equal(res.pts[:live], ro.pts[:live])
-        assert np.array_equal(res.parent[:live], ro.parent[:live])
-        assert np.array_equal(res.vcost[:live], ro.vcost[:live])
+    for rep in range(2):  # the team size stays: the next launch tries the team again (and, with the fault flag, falls back again)
+        b.launch()
+        b.sync()
+        assert b.team() == (8, rep + 1)
+        assert b.elapsed_ms() > 400.0  # the launch that timed out (0.5 s bounded wait) is part of the reported time
+        for q in range(Q):
+            res = b.get_result(q)
+            st, ro = refs[q]
+            live = ro.j + (1 if ro.found else 0)
+            assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal
+            assert np.array_equal(res.pts[:live], ro.pts[:live])
+            assert np.array_equal(res.parent[:live], ro.parent[:live])
+            assert np.array_equal(res.vcost[:live], ro.vcost[:live])
+        b.rearm()
     b.close()
 
 
@@ -504,6 +664,38 @@ def test_replanning_on_resident_frames_equals_uploaded_grids():
         assert ga == gb and list(Ta.edges) == list(Tb.edges)
         assert all(np.array_equal(Ta.nodes[v]["pt"], Tb.nodes[v]["pt"]) for v in Ta.nodes)
         assert [d["cost"] for _, _, d in Ta.edges(data=True)] == [d["cost"] for _, _, d in Tb.edges(data=True)]
+
+
+def test_resident_frames_are_invalidated_by_any_other_upload():
+    """set_og_resident -> set_og + plan -> set_og_resident must not silently plan on the other grid."""
+    from rrtplanner_amd.oggen import DeviceGrids
+
+    frames = perlin_occupancygrid(96, 96, thresh=0.33, frames=3, seed=5)
+    other = perlin_occupancygrid(96, 96, thresh=0.33, seed=8)
+    xs, xg = random_connected_pair(frames[1], np.random.default_rng(2))
+    p = amd.RRTStar(frames[0], 300, 16, pbar=False, seed=1)
+    grids = DeviceGrids(p.device_context(), 96, 96, thresh=0.33, frames=3, seed=5)
+    p.set_og_resident(grids, 1)
+    assert grids.valid()
+    p.plan(xs, xg)
+    p.set_og(other)  # an upload replaces the resident frames at the next plan()
+    try:
+        p.plan(xs, xg)
+    except IndexError:
+        pass
+    assert not grids.valid()
+    for k in (0, 1, 2):
+        with pytest.raises(RuntimeError):
+            p.set_og_resident(grids, k)
+    assert p.og is other  # the failed switch left the planner on the uploaded grid
+    # a second DeviceGrids on the same context evicts the first one as well
+    g2 = DeviceGrids(p.device_context(), 96, 96, thresh=0.33, frames=2, seed=6)
+    g3 = DeviceGrids(p.device_context(), 96, 96, thresh=0.33, frames=2, seed=7)
+    assert g3.valid() and not g2.valid()
+    with pytest.raises(RuntimeError):
+        p.set_og_resident(g2, 0)
+    p.set_og_resident(g3, 1)
+    assert np.array_equal(p.og, g3.host[1])
 
 
 def test_missing_grid_and_bad_arguments_fail_loudly():

@@ -116,9 +116,12 @@ def test_sharding_helpers():
     with pytest.raises(ValueError):
         multi.shard_queries(4, 2, 2)
     Q, stride = 3, 8
-    slab = np.zeros(Q * stride * 16, dtype=np.uint8)
-    v, nd, pa = multi.unpack_slab(slab, Q, stride)
-    assert v.shape == (Q, stride) and nd.dtype == np.uint32 and pa.dtype == np.int32
+    slab = np.zeros(multi.slab_bytes(Q, stride), dtype=np.uint8)
+    slab[-16:-12] = np.array([77], dtype=np.int32).view(np.uint8)
+    v, nd, pa, meta = multi.unpack_slab(slab, Q, stride)
+    assert v.shape == (Q, stride) and nd.dtype == np.uint32 and pa.dtype == np.int32 and meta.shape == (Q, 4) and meta[2, 0] == 77
+    with pytest.raises(ValueError):
+        multi.unpack_slab(slab[:-1], Q, stride)
 
 
 def test_build_graph_equals_call_by_call_construction():
@@ -213,3 +216,53 @@ def test_tree_digraph_is_lazy_and_equal_to_build_graph():
     assert p.route2gv(T, vgoal) == path  # and after materialisation
     T.add_edge(3, 9999, dist=1.0)  # an ordinary DiGraph from here on
     assert T.has_edge(3, 9999)
+
+
+def test_informed_sampler_helpers_match_the_reference_tables():
+    """The public sampler helpers of RRTStarInformed (rrt.py:579-651) on the host, against the reference's 2400-row
+    sample_ellipse table and rotation matrices (tests/golden/primitives.npz)."""
+    import orchelp
+
+    P = orchelp.golden("primitives.npz").z
+    W, H = P["ell_WH"]
+    p = amd.RRTStarInformed(np.zeros((int(W), int(H)), dtype=int), 10, 10, 5, pbar=False, seed=0)
+    for s, Cm in zip(P["rot_sg"], P["rot_C"]):
+        assert np.array_equal(p.rotation_to_world_frame(s[:2].astype(np.int64), s[2:].astype(np.int64)), Cm)
+    for row, want in zip(P["ell_in"][::7], P["ell_out"][::7]):
+        xs, xg = row[:2].astype(np.int64), row[2:4].astype(np.int64)
+        p.unitball = lambda u=row[5:7]: u
+        assert p.sample_ellipse(xs, xg, row[4]).tolist() == want.tolist()
+    del p.unitball
+    # unitball(): two scalar uniform draws, like rrt.py:582-586
+    g = np.random.default_rng(0)
+    r, th = g.uniform(0, 1), 2 * np.pi * g.uniform(0, 1)
+    assert np.array_equal(p.unitball(), np.array([np.sqrt(r) * np.cos(th), np.sqrt(r) * np.sin(th)]))
+    assert p.rand_gen.bit_generator.state == g.bit_generator.state
+    # get_ellipse_for_plt vs the vectorised form plan() uses for self.ellipses
+    xs, xg = np.array([10, 10]), np.array([250, 150])
+    Cm = p.rotation_to_world_frame(xs, xg)
+    xc, ma, mi, an = p.get_ellipse_for_plt(xs, xg, 300.0)
+    xc2, ma2, mi2, an2 = hostprep.ellipse_plot_params(Cm, xs, xg, np.array([300.0]))
+    assert np.array_equal(xc, xc2) and np.allclose([ma, mi, an], [ma2[0], mi2[0], an2[0]], rtol=1e-12)
+    assert amd.RRTStarInformed.least_cost(np.array([5.0, 1.0, 1.0, 3.0]), [0, 2, 1, 3]) == (2, 1.0)
+    assert amd.RRTStarInformed.least_cost(np.array([5.0, 1.0]), [1]) == (1, 1.0)
+    assert amd.RRTStarInformed.rad2deg(np.pi) == 180.0
+
+
+def test_host_go2goal_helper_follows_the_reference_contract():
+    """RRT.go2goal (rrt.py:284-332) as a host helper: cheapest visible vertex, arrays grown by one row, vgoal = j."""
+    from collections import defaultdict
+
+    og = np.zeros((20, 20), dtype=int)
+    og[10, 2:20] = 1  # a wall with a gap at y < 2
+    p = amd.RRTStandard(og, 4, pbar=False)
+    points = np.array([[2, 10], [5, 10], [9, 1], [2, 2]], dtype=np.int64)
+    vcosts = np.array([0.0, 3.0, 12.0, 8.0])
+    children, parents = defaultdict(list), {0: None, 1: 0, 2: 1, 3: 0}
+    vgoal, children, parents, pts2, vc2 = p.go2goal(vcosts, points, np.array([15, 1]), 4, children, parents)
+    assert vgoal == 4 and parents[4] == 2 and children[2] == [4]  # only vertex 2 sees the goal through the gap
+    assert pts2.shape == (5, 2) and pts2[4].tolist() == [15, 1] and vc2[4] == 12.0 + 6.0
+    # nothing sees the goal: vgoal = 0 (rrt.py:330-331), arrays unchanged
+    og[10, :] = 1
+    vgoal, _, _, pts3, vc3 = p.go2goal(vcosts, points, np.array([15, 1]), 4, defaultdict(list), {0: None})
+    assert vgoal == 0 and pts3.shape == (4, 2) and vc3.shape == (4,)

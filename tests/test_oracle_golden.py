@@ -212,3 +212,30 @@ def test_numpy_reference_like_harness_builds_the_oracles_tree():
     assert it == n and j == ro.j
     assert np.array_equal(pts[:j], ro.pts[:j]) and np.array_equal(vc[:j], ro.vcost[:j])
     assert all(par[c] == ro.parent[c] for c in range(1, j))
+
+
+# ------------------------------------------------------------------------------- bench-scale goldens from the real reference
+GBIG = orchelp.golden("plans_big_A.npz")
+
+
+@pytest.mark.parametrize("meta", GBIG.manifest, ids=[m["id"] for m in GBIG.manifest])
+def test_plan_bench_scale_and_grid_dtypes(meta):
+    """The oracle (and the host logic around it) against the reference at bench scale: query 0 of BASELINE config 4 on the
+    bench's own 1024x1024 grid (n = 20000), Informed RRT* on 400x400 (n = 6000), and the reference's 8 grid dtypes
+    (tests/test_rrt.py:8-17; a fractional value is an obstacle like any non-zero)."""
+    og = GBIG.grid(meta["grid"]).astype(np.int64)
+    if "og_dtype" in meta:
+        dt = {"int": int, "float": float}.get(meta["og_dtype"]) or getattr(np, meta["og_dtype"])
+        og = og.astype(dt)
+        if meta["fractional"]:
+            og[30, 30] = 0.25
+    p = orchelp.use_oracle(orchelp.make_planner(amd, meta, og))
+    T, gv = p.plan(np.array(meta["xstart"]), np.array(meta["xgoal"]))
+    orchelp.check_plan_against_golden(GBIG, meta, p, T, gv)
+
+
+def test_bench_grid_generator_has_not_drifted():
+    """bench.py regenerates its grid from the seed; the golden holds the grid the reference ran on."""
+    from rrtplanner_amd.oggen import perlin_occupancygrid
+
+    assert np.array_equal((perlin_occupancygrid(1024, 1024, thresh=0.33, seed=1) != 0).astype(np.uint8), GBIG.grid("bench1024"))

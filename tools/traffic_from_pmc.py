@@ -1,8 +1,9 @@
-"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
-profiles/r01_traffic.json, which bench.py reports as roofline.traffic.
+"""Turn rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only) into
+profiles/r02_traffic.json, which bench.py reports as roofline.traffic when config, queries, n, team size and pipeline match.
 
-    python tools/traffic_from_pmc.py CONFIG QUERIES N FETCH_DIR WRITE_DIR [CONFIG QUERIES N FETCH_DIR WRITE_DIR ...]
+    python tools/traffic_from_pmc.py CONFIG QUERIES N TEAM PIPELINED FETCH_DIR WRITE_DIR [... 7 more ...]
 
+TEAM = workers per query (bench line: cus_per_query minus the committer), PIPELINED = 0 / 1.
 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB and gfx950 counts a
 128-byte read request as 64 bytes (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
 import csv
@@ -28,14 +29,14 @@ def mean_counter(dirname, counter):
 
 def main(argv):
     entries = []
-    for k in range(0, len(argv), 5):
-        cfg, q, n, fdir, wdir = argv[k:k + 5]
+    for k in range(0, len(argv), 7):
+        cfg, q, n, team, pipe, fdir, wdir = argv[k:k + 7]
         f, w = mean_counter(fdir, "FETCH_SIZE"), mean_counter(wdir, "WRITE_SIZE")
-        entries.append(dict(config=int(cfg), queries_per_gpu=int(q), n=int(n), fetch_size_kb=f, write_size_kb=w,
-                            hbm_bytes_per_launch=int((2 * f + w) * 1024), note=NOTE))
-    json.dump({"entries": entries}, open("profiles/r01_traffic.json", "w"), indent=1)
+        entries.append(dict(config=int(cfg), queries_per_gpu=int(q), n=int(n), team=int(team), pipelined=bool(int(pipe)),
+                            fetch_size_kb=f, write_size_kb=w, hbm_bytes_per_launch=int((2 * f + w) * 1024), note=NOTE))
+    json.dump({"entries": entries}, open("profiles/r02_traffic.json", "w"), indent=1)
     for e in entries:
-        print(e["config"], e["hbm_bytes_per_launch"])
+        print(e["config"], e["queries_per_gpu"], e["team"], e["pipelined"], e["hbm_bytes_per_launch"])
 
 
 if __name__ == "__main__":

@@ -69,6 +69,7 @@ int main() {
     (void)hipMemcpy(dq, hq.data(), 4096, hipMemcpyHostToDevice);
     size_t lds = nchunks * 16384;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    double dot2_256 = 0.0;
     auto run = [&](auto kern, const char* name) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int blocks : {1, 256}) {
@@ -78,6 +79,7 @@ int main() {
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             double pairs = (double)reps * B * nchunks * 4096;
+            if (name[0] == 'd' && blocks == 256) dot2_256 = pairs / (ms * 1e6);
             printf("%-10s blocks=%3d: %.3f ms -> %.2f pairs/ns/CU = %.1f pairs/cycle/CU @2.4GHz ; %.0f cyc per 16-sample step of 4096 nodes\n", name, blocks, ms,
                    pairs / (ms * 1e6), pairs / (ms * 1e6) / 2.4, ms * 1e6 * 2.4 / (reps * nchunks));
         }
@@ -85,5 +87,8 @@ int main() {
     run(k<0>, "dot2");
     run(k<1>, "mad24");
     run(k<2>, "f32");
+    // the figure bench.py's roofline.inner uses as the per-CU peak of the scan's inner loop (all 256 CUs busy, the kernel's own
+    // v_pk_sub_i16 + v_dot2_i32_i16 + v_min3_u32 form, time-based: no clock assumption)
+    printf("JSON {\"pairs_per_ns_per_cu\": %.4f, \"variant\": \"dot2, 16 samples in SGPRs, 4 nodes per lane from LDS, 256 workgroups of 1024 threads\", \"source\": \"tools/ubench/pair_rate.hip\"}\n", dot2_256);
     return 0;
 }
