@@ -104,6 +104,7 @@ def main():
                     help="cap on the CUs per query (default: the largest team for which all teams are resident together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the informational batched leg (configs[3] share of one GPU)")
+    ap.add_argument("--rewire-leg", action="store_true", help="add an informational leg: query 0 with the opt-in true rewire (not the reference's behaviour)")
     args = ap.parse_args()
 
     # rank 0 prints exactly ONE line on stdout: route everything else that writes to fd 1 (RCCL's banner, library
@@ -264,6 +265,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(og8, cfg, pairs[0], free, states[0], ub_cache.get(0), results[0])
         if world == 1 and args.config == 2 and not args.no_batched:
             out["batched"] = batched_leg(ctx, og, og8, free, _ffi, hostprep)
+        if world == 1 and args.rewire_leg and alg >= 1:
+            out["rewire_correct"] = rewire_leg(ctx, og8, cfg, pairs[0], free, states[0], _ffi, hostprep)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
@@ -317,6 +320,38 @@ def batched_leg(ctx, og, og8, free, _ffi, hostprep):
                          "traffic": measured_traffic(4, Q, n, cus, pipelined),
                          "achieved_is": "algorithmic (model) bytes per second, not measured HBM traffic",
                          "inner": inner_roof(sum(r.c.sum_j for r in res), kms / steps, cus * Q)}}
+
+
+def rewire_leg(ctx, og8, cfg, pair, free, state0, _ffi, hostprep):
+    """Informational: query 0 of the workload with the opt-in TRUE rewire (RRT_FLAG_REWIRE; one-sample-per-iteration kernel, one
+    CU).  Outside reference parity by definition; checked against the oracle's restatement of the same semantics."""
+    import oracle
+
+    n, alg = cfg["n"], 1
+    xs, xg = pair
+    rng = np.random.default_rng(0)
+    rng.bit_generator.state = state0
+    samples = hostprep.draw_free_samples(rng, free, n)
+    r2 = hostprep.radius_threshold(cfg["r_rewire"])
+    b = _ffi.Batch(ctx, 1, n, rewire=True)
+    qu, keep = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2)
+    b.set_query(0, qu)
+    b.launch(); b.sync()
+    steps, kms, t0 = 3, 0.0, time.perf_counter()
+    for _ in range(steps):
+        b.rearm(); b.launch(); b.sync()
+        kms += b.elapsed_ms()
+    dt = time.perf_counter() - t0
+    r = b.get_result(0, arrays=False)
+    t1 = time.perf_counter()
+    st, ro = oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=r2, logs=False, rewire=True)
+    t_or = time.perf_counter() - t1
+    if (r.c.status, r.c.j, r.c.vgoal, r.c.n_rewired, r.c.n_propagated) != (st, ro.j, ro.vgoal, ro.n_rewired, ro.n_propagated):
+        raise SystemExit("bench: rewire leg differs from the oracle")
+    b.close()
+    return {"workload": f"RRT* with rewire=\"correct\" (RRT_FLAG_REWIRE), query 0, n={n}", "value": (r.c.j - 1) * steps / dt, "unit": "nodes/s",
+            "kernel_ms": kms / steps, "kernel": "rrt_expand_kernel<true>", "cus_per_query": 1, "n_rewired": int(r.c.n_rewired),
+            "n_propagated": int(r.c.n_propagated), "cpu_oracle_nodes_per_s": (ro.j - 1) / t_or, "reference_parity": "none (not the reference's behaviour)"}
 
 
 def cpu_baseline(og8, cfg, pair, free, state0, ub, dev0):

@@ -42,6 +42,9 @@ extern "C" {
                                   and the batch must finish with one CU per query */
 #define RRT_FLAG_NOPIPE 16u /* teams of 8 and more CUs: do not pipeline super-blocks (the commit of block s under the resolution
                               of block s + 1; RRTStandard / RRTStar only) */
+#define RRT_FLAG_REWIRE 32u /* opt-in TRUE RRT* rewire with cost propagation -- NOT the reference's behaviour: its
+                              rewire step never fires (rrt.py:532-536 prices the rewire with vcosts[vn] + d, never below vcosts[vn]).
+                              Semantics: oracle/rrt_oracle.c; runs on the one-sample-per-iteration kernel.  Default off. */
 #define RRT_FLAG_TEAM_MAX(g) ((uint32_t)(g) << 8) /* cap the team size at g CUs per query (g = 2, 4, ... 64; 0 = no cap) */
 
 typedef struct rrt_ctx rrt_ctx;
@@ -82,6 +85,8 @@ typedef struct rrt_result {
     int64_t sum_near;
     int64_t sum_cells_cand;
     int64_t n_los_cand;
+    int64_t n_rewired;    /* RRT_FLAG_REWIRE: nodes re-parented / descendant costs recomputed (0 otherwise: rrt.py:536 is never true) */
+    int64_t n_propagated;
 } rrt_result;
 
 /* ---- context / grid -------------------------------------------------------------- */

@@ -39,6 +39,7 @@ class _Plan(C.Structure):
         ("j", C.c_int32), ("vgoal", C.c_int32), ("found", C.c_int32), ("i_switch", C.c_int32), ("rows", C.c_int32),
         ("sum_j", C.c_int64), ("sum_cells_nn", C.c_int64), ("sum_near", C.c_int64), ("sum_cells_cand", C.c_int64),
         ("n_rewired", C.c_int64),
+        ("rewire", C.c_int32), ("pad_", C.c_int32), ("n_propagated", C.c_int64),
     ]
 
 
@@ -113,8 +114,8 @@ class PlanResult:
     pass
 
 
-def plan(og8, n, alg, xs, xg, samples, r2_rewire=0, r_goal=0.0, unitball=None, ub_offset=0, Cmat=None, logs=True):
-    """Run orc_plan once.  Returns (status, PlanResult)."""
+def plan(og8, n, alg, xs, xg, samples, r2_rewire=0, r_goal=0.0, unitball=None, ub_offset=0, Cmat=None, logs=True, rewire=False):
+    """Run orc_plan once.  Returns (status, PlanResult).  rewire=True: the opt-in true RRT* rewire (not the reference's)."""
     og8 = np.ascontiguousarray(og8, dtype=np.uint8)
     samples = np.ascontiguousarray(samples, dtype=np.int32)
     assert samples.shape == (n, 2)
@@ -125,6 +126,7 @@ def plan(og8, n, alg, xs, xg, samples, r2_rewire=0, r_goal=0.0, unitball=None, u
     p.xg[0], p.xg[1] = int(xg[0]), int(xg[1])
     p.r2_rewire, p.r_goal = int(r2_rewire), float(r_goal)
     p.samples = samples.ctypes.data
+    p.rewire = 1 if rewire else 0
     if unitball is not None:
         unitball = np.ascontiguousarray(unitball, dtype=np.float64)
         p.unitball = unitball.ctypes.data
@@ -147,6 +149,6 @@ def plan(og8, n, alg, xs, xg, samples, r2_rewire=0, r_goal=0.0, unitball=None, u
         p.cbest_log, p.jlog = r.cbest_log.ctypes.data, r.jlog.ctypes.data
     status = lib().orc_plan(C.byref(p))
     for k in ("j", "vgoal", "found", "i_switch", "rows", "sum_j", "sum_cells_nn", "sum_near", "sum_cells_cand",
-              "n_rewired"):
+              "n_rewired", "n_propagated"):
         setattr(r, k, getattr(p, k))
     return status, r

@@ -58,7 +58,11 @@ typedef struct {
     int64_t sum_cells_nn;   /* Bresenham cells visited nearest -> new */
     int64_t sum_near;       /* sum over accepted iterations of |within| restricted to live rows */
     int64_t sum_cells_cand; /* Bresenham cells visited by choose-parent line-of-sight tests */
-    int64_t n_rewired;      /* times the rewire predicate rrt.py:536 was true (always 0) */
+    int64_t n_rewired;      /* rewire 0: times the predicate rrt.py:536 was true (always 0); rewire 1: nodes re-parented */
+    /* ---- opt-in true RRT* rewire (NOT the reference's behaviour, no reference parity) ---- */
+    int32_t rewire;         /* input: 0 = the reference's (vacuous) rewire scan, 1 = "correct" rewire with cost propagation */
+    int32_t pad_;
+    int64_t n_propagated;   /* rewire 1: descendant costs recomputed */
 } orc_plan_t;
 
 /* rrt.py:10-24  r2norm on an integer difference vector: sqrt(x0*x0 + x1*x1). */
@@ -233,6 +237,37 @@ static int orc_go2goal(orc_plan_t *p) {
     return ORC_OK;
 }
 
+/* ---- opt-in "correct" rewire (build-defined; contrast rrt.py:531-546) -------------------------------------------------
+ * The reference prices a rewire with cost(vn -> xnew) = vcosts[vn] + d, which can never be below vcosts[vn]: its rewire
+ * never fires.  With rewire = 1 the textbook step runs instead, defined so that a parallel machine can
+ * take all decisions of one insertion at once:
+ *   1. decide: for vn in vnear (ascending; the near set taken BEFORE the insertion, like rrt.py:513), with the costs as
+ *      they stand right after the insertion:  c = vcosts[vnew] + r2norm(points[vn] - xnew);  vn is re-parented iff
+ *      c < vcosts[vn] (strict) and collisionfree(og, points[vn], xnew)  (the call direction of rrt.py:537).
+ *   2. apply: parents[vn] = vnew, vcosts[vn] = c for every such vn.
+ *   3. propagate: every descendant d of a re-parented node, parents before children: vcosts[d] = vcosts[parents[d]] +
+ *      r2norm(points[d] - points[parents[d]]).  (The reference propagates nothing, rrt.py:546.)
+ * Costs never decrease along a root path (each is fl(parent cost + non-negative distance)), so an ancestor of vnew can
+ * never pass the strict test in 1: the tree stays a tree.  Informed: the best solution vertex is the first minimum of
+ * the CURRENT costs over the solution vertices in insertion order (rrt.py:627-633 evaluated on the updated costs). */
+typedef struct {
+    int32_t *first_child, *next_sib, *prev_sib; /* child lists: prepend on insert, O(1) unlink */
+    int32_t *queue;
+} orc_kids;
+
+static void orc_kids_link(orc_kids *k, int32_t parent, int32_t child) {
+    k->prev_sib[child] = -1;
+    k->next_sib[child] = k->first_child[parent];
+    if (k->first_child[parent] >= 0) k->prev_sib[k->first_child[parent]] = child;
+    k->first_child[parent] = child;
+}
+
+static void orc_kids_unlink(orc_kids *k, int32_t parent, int32_t child) {
+    const int32_t p = k->prev_sib[child], nx = k->next_sib[child];
+    if (p >= 0) k->next_sib[p] = nx; else k->first_child[parent] = nx;
+    if (nx >= 0) k->prev_sib[nx] = p;
+}
+
 /* The three plan() loops: rrt.py:407-447 (Standard), :487-556 (Star), :678-758 (Informed). */
 int orc_plan(orc_plan_t *p) {
     const int32_t n = p->n, W = p->W, H = p->H;
@@ -250,6 +285,21 @@ int orc_plan(orc_plan_t *p) {
     p->vcost[0] = 0.0;
     uint8_t *sampled = (uint8_t *)calloc((size_t)W * H, 1); /* rrt.py:407 `sampled` set */
     int32_t *vnear = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    const int rw = (p->rewire == 1 && p->alg >= 1);
+    orc_kids kids = {0, 0, 0, 0};
+    int32_t *vsoln = NULL, *rw_v = NULL;
+    double *rw_c = NULL;
+    if (rw) {
+        kids.first_child = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+        kids.next_sib = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+        kids.prev_sib = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+        kids.queue = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+        vsoln = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+        rw_v = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+        rw_c = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+        for (int32_t k = 0; k <= n; k++) kids.first_child[k] = kids.next_sib[k] = kids.prev_sib[k] = -1;
+    }
+    p->n_propagated = 0;
     int32_t i = 0, j = 1;
     /* Informed: vsoln running first-min of vcosts (rrt.py:627-633), costs never change (no rewire) */
     int32_t nsoln = 0, vbest_soln = -1;
@@ -313,20 +363,60 @@ int orc_plan(orc_plan_t *p) {
             p->pts[2 * vnew + 1] = xn[1];
             p->vcost[vnew] = cbest;
             p->parent[vnew] = vbest;
-            if (p->alg >= 1) { /* rrt.py:531-546 rewire scan: predicate never true with the default cost */
+            if (p->alg >= 1 && !rw) { /* rrt.py:531-546 rewire scan: predicate never true with the default cost */
                 for (int32_t t = 0; t < m; t++) {
                     int32_t vn = vnear[t];
                     double cmaybe = orc_cost(p, vn, xn[0], xn[1]);
                     if (cmaybe < p->vcost[vn]) p->n_rewired++; /* would need the reference's stale-cost rewire */
                 }
             }
+            int32_t nrw = 0;
+            if (rw) { /* the opt-in rewire, see above */
+                orc_kids_link(&kids, vbest, vnew);
+                for (int32_t t = 0; t < m; t++) { /* 1. decide */
+                    int32_t vn = vnear[t];
+                    double c = cbest + orc_r2norm_i((int64_t)p->pts[2 * vn] - xn[0], (int64_t)p->pts[2 * vn + 1] - xn[1]);
+                    if (c < p->vcost[vn] && orc_collisionfree(p->og, W, H, p->pts[2 * vn], p->pts[2 * vn + 1], xn[0], xn[1], NULL)) {
+                        rw_v[nrw] = vn;
+                        rw_c[nrw] = c;
+                        nrw++;
+                    }
+                }
+                int32_t qh = 0, qt = 0;
+                for (int32_t t = 0; t < nrw; t++) { /* 2. apply */
+                    int32_t vn = rw_v[t];
+                    orc_kids_unlink(&kids, p->parent[vn], vn);
+                    orc_kids_link(&kids, vnew, vn);
+                    p->parent[vn] = vnew;
+                    p->vcost[vn] = rw_c[t];
+                    kids.queue[qt++] = vn;
+                }
+                p->n_rewired += nrw;
+                while (qh < qt) { /* 3. propagate, parents before children */
+                    int32_t u = kids.queue[qh++];
+                    for (int32_t c = kids.first_child[u]; c >= 0; c = kids.next_sib[c]) {
+                        p->vcost[c] = p->vcost[u] + orc_r2norm_i((int64_t)p->pts[2 * c] - p->pts[2 * u], (int64_t)p->pts[2 * c + 1] - p->pts[2 * u + 1]);
+                        kids.queue[qt++] = c;
+                        p->n_propagated++;
+                    }
+                }
+            }
             if (p->alg == 2) { /* rrt.py:744-745 */
                 if (orc_r2norm_i((int64_t)xn[0] - p->xg[0], (int64_t)xn[1] - p->xg[1]) < p->r_goal) {
+                    if (rw) vsoln[nsoln] = vnew;
                     nsoln++;
                     if (p->vcost[vnew] < cmin_soln) { /* np.argmin: first minimum */
                         cmin_soln = p->vcost[vnew];
                         vbest_soln = vnew;
                     }
+                }
+                if (rw && nrw > 0 && nsoln > 0) { /* costs moved: rrt.py:627-633 on the current costs, first minimum in insertion order */
+                    cmin_soln = INFINITY;
+                    for (int32_t t = 0; t < nsoln; t++)
+                        if (p->vcost[vsoln[t]] < cmin_soln) {
+                            cmin_soln = p->vcost[vsoln[t]];
+                            vbest_soln = vsoln[t];
+                        }
                 }
             }
             j++;
@@ -336,6 +426,15 @@ int orc_plan(orc_plan_t *p) {
     p->j = j;
     free(sampled);
     free(vnear);
+    if (rw) {
+        free(kids.first_child);
+        free(kids.next_sib);
+        free(kids.prev_sib);
+        free(kids.queue);
+        free(vsoln);
+        free(rw_v);
+        free(rw_c);
+    }
     if (status != ORC_OK) return status;
     return orc_go2goal(p);
 }

@@ -28,13 +28,15 @@ FLAG_SERIAL = 2
 FLAG_NOTEAM = 4
 FLAG_TEAM_FAULT = 8
 FLAG_NOPIPE = 16
+FLAG_REWIRE = 32
 
 
-def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=True):
+def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=True, rewire=False):
     """flags word of rrt_plan / rrt_batch_create.  team: None = as many CUs per query as fit (up to 64), 1 = one CU,
     2..64 = cap on the team size; pipe = False: teams of 8 and more do not pipeline super-blocks; team_fault = the
     fault-injection flag of the tests."""
     f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_TEAM_FAULT if team_fault else 0) | (0 if pipe else FLAG_NOPIPE)
+    f |= FLAG_REWIRE if rewire else 0  # the opt-in true rewire (not the reference's behaviour)
     if team == 1:
         f |= FLAG_NOTEAM
     elif team is not None:
@@ -79,7 +81,7 @@ class Result(C.Structure):
         ("status", C.c_int32), ("j", C.c_int32), ("vgoal", C.c_int32), ("found", C.c_int32),
         ("i_switch", C.c_int32), ("rows", C.c_int32),
         ("sum_j", C.c_int64), ("sum_cells_nn", C.c_int64), ("sum_near", C.c_int64), ("sum_cells_cand", C.c_int64),
-        ("n_los_cand", C.c_int64),
+        ("n_los_cand", C.c_int64), ("n_rewired", C.c_int64), ("n_propagated", C.c_int64),
     ]
 
 
@@ -179,7 +181,7 @@ class ResultArrays:
 
     def __getattr__(self, k):  # scalars live in the C struct
         if k in ("status", "j", "vgoal", "found", "i_switch", "rows", "sum_j", "sum_cells_nn", "sum_near",
-                 "sum_cells_cand", "n_los_cand"):
+                 "sum_cells_cand", "n_los_cand", "n_rewired", "n_propagated"):
             return getattr(self.c, k)
         raise AttributeError(k)
 
@@ -282,9 +284,9 @@ class Context:
         self.allreduce([0.0])
 
     # ---- one-shot ----
-    def plan(self, query, n, logs=False, serial=False, team=None, team_fault=False, pipe=True):
+    def plan(self, query, n, logs=False, serial=False, team=None, team_fault=False, pipe=True, rewire=False):
         res = ResultArrays(n, logs)
-        flags = kernel_flags(logs, serial, team, team_fault, pipe)
+        flags = kernel_flags(logs, serial, team, team_fault, pipe, rewire)
         rc = lib().rrt_plan(self._h, C.byref(query), flags, C.byref(res.c))
         _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
         return rc, res
@@ -349,10 +351,10 @@ class Batch:
     """Q independent queries resident on the device (rrt_batch_*)."""
 
     def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False, team=None, team_fault: bool = False,
-                 pipe: bool = True):
+                 pipe: bool = True, rewire: bool = False):
         self.ctx, self.Q, self.n_cap, self.logs = ctx, int(Q), int(n_cap), logs
         self._h = C.c_void_p()
-        flags = kernel_flags(logs, serial, team, team_fault, pipe)
+        flags = kernel_flags(logs, serial, team, team_fault, pipe, rewire)
         _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, flags, C.byref(self._h)))
         if not hasattr(ctx, "_batches"):
             ctx._batches = weakref.WeakSet()

@@ -63,6 +63,9 @@ struct rrt_batch {
     int32_t *d_parent = nullptr, *d_nearest_log = nullptr, *d_j_log = nullptr;
     uint8_t *d_accept_log = nullptr;
     uint2 *d_spill = nullptr;
+    int32_t *d_kids = nullptr;      // RRT_FLAG_REWIRE: [3][Q][node_stride] first child / next sibling / previous sibling
+    uint32_t *d_frontier = nullptr; //                  [Q][2 * node_stride]
+    int32_t *d_vsoln = nullptr;     //                  [Q][node_stride]
     uint4 *d_cellrec = nullptr;    // block kernel: near-set records, [Q][rec_stride]
     uint32_t *d_cellcnt = nullptr; // [Q][MAX_CELLS]
     int64_t rec_stride = 0;
@@ -342,7 +345,7 @@ extern "C" int rrt_batch_destroy(rrt_batch *b) {
     (void)hipStreamSynchronize(b->ctx->stream);
     void *ptrs[] = {b->d_desc,  b->d_samples,   b->d_slab,        b->d_bitmap, b->d_unitball,  b->d_cellrec,
                     b->d_spill, b->d_cbest_log, b->d_nearest_log, b->d_j_log,  b->d_accept_log, b->d_cellcnt,
-                    b->d_team};
+                    b->d_team,  b->d_kids,      b->d_frontier,    b->d_vsoln};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -369,7 +372,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->node_stride = ((n_cap + 1 + CHUNK - 1) / CHUNK) * CHUNK;
     b->bitmap_words = (int32_t)(((size_t)ctx->W * ctx->H + 31) / 32);
     int chunks = (n_cap + 1 + CHUNK - 1) / CHUNK;
-    b->use_block = !(flags & RRT_FLAG_SERIAL);
+    b->use_block = !(flags & (RRT_FLAG_SERIAL | RRT_FLAG_REWIRE));  // the opt-in rewire runs on the one-sample-per-iteration kernel
     if (b->use_block && !(flags & RRT_FLAG_NOTEAM)) {
         // the largest team (CUs per query) with every member of every team resident at once.  Blocks are dealt round-robin
         // to the 8 XCDs, so block = member * stride + query with stride = 0 (mod 8) keeps a team of up to 16 on one XCD (one
@@ -440,6 +443,11 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         ALLOC(b->d_cellcnt, q * (size_t)MAX_CELLS * sizeof(uint32_t));
         if (b->team > 1) ALLOC(b->d_team, q * (size_t)TEAM_BYTES);
     }
+    if (flags & RRT_FLAG_REWIRE) {
+        ALLOC(b->d_kids, 3 * q * b->node_stride * sizeof(int32_t));
+        ALLOC(b->d_frontier, 2 * q * b->node_stride * sizeof(uint32_t));
+        ALLOC(b->d_vsoln, q * b->node_stride * sizeof(int32_t));
+    }
     if (flags & RRT_FLAG_LOGS) {
         ALLOC(b->d_nearest_log, q * n_cap * sizeof(int32_t));
         ALLOC(b->d_accept_log, q * n_cap * sizeof(uint8_t));
@@ -473,6 +481,7 @@ static void arm_desc(QDesc &d) {
     d.ub_offset = 0;
     d.ub_count = 0;
     d.sum_j = d.sum_cells_nn = d.sum_near = d.sum_cells_cand = d.n_los_cand = 0;
+    d.n_rewired = d.n_propagated = 0;
     for (auto &c : d.cyc) c = 0;
     for (auto &c : d.wcyc) c = 0;
 }
@@ -577,6 +586,14 @@ static BatchView make_view(rrt_batch *b) {
     v.Q = b->Q;
     v.team_qpad = b->team_qpad;
     v.team_fault = (b->flags & RRT_FLAG_TEAM_FAULT) ? 1 : 0;
+    if (b->d_kids) {
+        const size_t qs = (size_t)b->Q * b->node_stride;
+        v.kid_first = b->d_kids;
+        v.kid_next = b->d_kids + qs;
+        v.kid_prev = b->d_kids + 2 * qs;
+        v.frontier = b->d_frontier;
+        v.vsoln = b->d_vsoln;
+    }
     return v;
 }
 
@@ -666,11 +683,15 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     const size_t lds = expand_lds_bytes(b->lds_chunks);
     const size_t lds_static = (size_t)NWAVE * WCAP * sizeof(uint2) + 2 * NWAVE * (sizeof(Slot) + sizeof(BSlot));
     if ((int)(lds + lds_static) > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds + lds_static, ctx->max_lds);
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rrt_expand_kernel),
+    const bool rw = (b->flags & RRT_FLAG_REWIRE) != 0;
+    HIPCHK(ctx, hipFuncSetAttribute(rw ? reinterpret_cast<const void *>(rrt_expand_kernel<true>) : reinterpret_cast<const void *>(rrt_expand_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
-    hipLaunchKernelGGL(rrt_expand_kernel, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
+    if (rw)
+        hipLaunchKernelGGL(rrt_expand_kernel<true>, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
+    else
+        hipLaunchKernelGGL(rrt_expand_kernel<false>, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     b->timed = true;
@@ -746,6 +767,8 @@ extern "C" int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out) {
     out->sum_near = (int64_t)d.sum_near;
     out->sum_cells_cand = (int64_t)d.sum_cells_cand;
     out->n_los_cand = (int64_t)d.n_los_cand;
+    out->n_rewired = (int64_t)d.n_rewired;
+    out->n_propagated = (int64_t)d.n_propagated;
     const int live = d.j + (d.found ? 1 : 0);
     if (out->pts) {
         std::vector<uint32_t> tmp((size_t)live);

@@ -44,6 +44,7 @@ struct QDesc {
     unsigned long long sum_j, sum_cells_nn, sum_near, sum_cells_cand, n_los_cand;
     unsigned long long wcyc[32]; // diagnostic build: per-wave cycles in the block kernel's owner phase [0..15] and its LoS part [16..31]
     unsigned long long cyc[6];  // diagnostic build (-DRRT_STAMPS): wave-0 cycles in scan / pre-barrier / barrier / B+C / D / go2goal
+    unsigned long long n_rewired, n_propagated;  // opt-in true rewire (RRT_FLAG_REWIRE): nodes re-parented, descendant costs recomputed
 };
 
 struct BatchView {
@@ -68,6 +69,10 @@ struct BatchView {
     unsigned char *team;      // [Q][TEAM_BYTES]    block kernel with teams: sync words, state, exchanged records
     int32_t Q, team_qpad;     // queries of the batch; block stride between the members of a team (block = member * team_qpad + query)
     int32_t team_fault;       // testing: member 1 of every team leaves at once (the others' hand-offs time out)
+    // opt-in true rewire (RRT_FLAG_REWIRE; serial kernel only), null otherwise
+    int32_t *kid_first, *kid_next, *kid_prev;  // [Q][node_stride] child lists: first child, next / previous sibling (-1 = none)
+    uint32_t *frontier;                        // [Q][2 * node_stride] two propagation frontiers
+    int32_t *vsoln;                            // [Q][node_stride] Informed: solution vertices in insertion order
 };
 
 constexpr int MAX_CELLS = 4096;  // cells per query (their fill counts live in LDS: 16 KiB)
@@ -315,11 +320,17 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
     } while (0)
 #endif
 
+// RW = true: the opt-in true RRT* rewire of SURVEY.md 8(f) row 4 (NOT the reference's behaviour; oracle/rrt_oracle.c states
+// the semantics): after an insertion every near-set entry vn with vcost[vnew] + dist < vcost[vn] and a free line of sight
+// vn -> xnew is re-parented to the new node, all decisions taken against the costs right after the insertion; then the costs
+// of the re-parented nodes' descendants are recomputed level by level over explicit child lists.
+template <bool RW>
 __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // node cache: lds_chunks * 16 KiB
     __shared__ __attribute__((aligned(16))) u32x2 wlist_lds[NWAVE * WCAP];
     __shared__ __attribute__((aligned(16))) Slot slots[2 * NWAVE];
     __shared__ __attribute__((aligned(16))) BSlot bslots[2 * NWAVE];
+    __shared__ uint32_t rw_cnt[2];  // RW: re-parented nodes of this insertion / fill of the next propagation frontier
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     const int q = (int)blockIdx.x;
     QDesc *D = bv.desc + q;
@@ -364,6 +375,14 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
     unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
 #endif
+    // RW: child lists, propagation frontiers, solution vertices
+    int32_t *kid_first = RW ? bv.kid_first + (size_t)q * bv.node_stride : nullptr;
+    int32_t *kid_next = RW ? bv.kid_next + (size_t)q * bv.node_stride : nullptr;
+    int32_t *kid_prev = RW ? bv.kid_prev + (size_t)q * bv.node_stride : nullptr;
+    uint32_t *front0 = RW ? bv.frontier + (size_t)q * 2 * bv.node_stride : nullptr;
+    uint32_t *front1 = RW ? front0 + bv.node_stride : nullptr;
+    int32_t *vsoln = RW ? bv.vsoln + (size_t)q * bv.node_stride : nullptr;
+    unsigned long long n_rewired = D->n_rewired, n_propagated = D->n_propagated;
 
     // Informed: constants of the ellipse transform (rrt.py:590, :621)
     const double xc0 = ((double)(D->xs[0] + D->xg[0])) / 2.0, xc1 = ((double)(D->xs[1] + D->xg[1])) / 2.0;
@@ -676,9 +695,122 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                 c_ell = cmin_soln + sqrt_u32(dist2(xg, xq));
             }
         }
-        pend = xq;
-        pend_cost = cbest;
-        pend_valid = true;
+        if (RW) {
+            // ---------------- E: the opt-in rewire ----------------
+            if (t == 0) {
+                rw_cnt[0] = 0;
+                const int32_t f = kid_first[vbest];  // link the new node under its parent (prepend)
+                kid_prev[j] = -1;
+                kid_next[j] = f;
+                kid_first[j] = -1;
+                if (f >= 0) kid_prev[f] = j;
+                kid_first[vbest] = j;
+                if (informed && dist2(xq, xg) < goal_d2) vsoln[nsoln - 1] = j;
+            }
+            __syncthreads();  // the insertion is visible, the counter is clear
+            // E1 decide: every wave goes through its own near-set entries (the list its scan filled before the insertion)
+            if (star) {
+                for (uint32_t base = 0; base < wcnt; base += 64) {
+                    const uint32_t c = base + (uint32_t)lane;
+                    u32x2 e = {NONE, 0u};
+                    if (c < wcnt) e = (c < (uint32_t)WCAP) ? wl.list[c] : wl.spill[c - WCAP];
+                    double cth = f64_inf();
+                    bool cand = false;
+                    if (c < wcnt) {
+                        cth = cbest + sqrt_u32(e.y);
+                        cand = cth < vcost[e.x];
+                    }
+                    unsigned long long m = __ballot(cand);
+                    while (m) {
+                        const int l = (int)__builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t vr = (uint32_t)__builtin_amdgcn_readlane((int)e.x, l);
+                        int cc = 0;
+                        const uint32_t pv = ((int)vr < lds_nodes) ? nodes_lds[vr] : nodes_g[vr];
+                        if (los_wave(og, H, pv, xq, lane, cc) && lane == l) {
+                            const uint32_t pos = __hip_atomic_fetch_add(&rw_cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            front0[pos] = vr;
+                            vcost[vr] = cth;  // each node is in one list only: no other lane reads or writes this cost in E1
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            uint32_t fcnt = rw_cnt[0];
+            if (fcnt > 0) {
+                n_rewired += fcnt;
+                // E2 apply: re-link the nodes one after the other (two of them may share a parent or be siblings)
+                if (t == 0) {
+                    for (uint32_t r = 0; r < fcnt; ++r) {
+                        const int32_t vr = (int32_t)front0[r];
+                        const int32_t po = parent[vr], pr = kid_prev[vr], nx = kid_next[vr];
+                        if (pr >= 0) kid_next[pr] = nx; else kid_first[po] = nx;
+                        if (nx >= 0) kid_prev[nx] = pr;
+                        const int32_t f = kid_first[j];
+                        kid_prev[vr] = -1;
+                        kid_next[vr] = f;
+                        if (f >= 0) kid_prev[f] = vr;
+                        kid_first[j] = vr;
+                        parent[vr] = j;
+                    }
+                }
+                // E3 propagate, level by level
+                uint32_t *cur = front0, *nxt = front1;
+                while (fcnt > 0) {
+                    if (t == 0) rw_cnt[1] = 0;
+                    __syncthreads();  // links / the previous level's costs are visible, the counter is clear
+                    for (uint32_t f = (uint32_t)t; f < fcnt; f += TPB) {
+                        const uint32_t u = cur[f];
+                        const double cu = vcost[u];
+                        const uint32_t xu = nodes_g[u];
+                        for (int32_t c = kid_first[u]; c >= 0; c = kid_next[c]) {
+                            vcost[c] = cu + sqrt_u32(dist2(nodes_g[c], xu));
+                            nxt[__hip_atomic_fetch_add(&rw_cnt[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = (uint32_t)c;
+                        }
+                    }
+                    __syncthreads();
+                    fcnt = rw_cnt[1];
+                    n_propagated += fcnt;
+                    uint32_t *tmp = cur;
+                    cur = nxt;
+                    nxt = tmp;
+                }
+                if (informed && nsoln > 0) {  // costs moved: first minimum of the current costs over the solution vertices
+                    double bc = f64_inf();
+                    uint32_t bi = NONE;
+                    for (int k = t; k < nsoln; k += TPB) {
+                        const double c = vcost[vsoln[k]];
+                        if (key_lt(c, (uint32_t)k, bc, bi)) {
+                            bc = c;
+                            bi = (uint32_t)k;
+                        }
+                    }
+                    wave_min_f64_idx(bc, bi);
+                    __syncthreads();  // bslots may still be read by a slower wave
+                    if (lane == 0) {
+                        bslots[wave].pc = bc;
+                        bslots[wave].pi = bi;
+                    }
+                    __syncthreads();
+                    double rc = f64_inf();
+                    uint32_t ri = NONE;
+                    if (lane < NWAVE) {
+                        rc = bslots[lane].pc;
+                        ri = bslots[lane].pi;
+                    }
+                    wave_min_f64_idx(rc, ri);
+                    cmin_soln = rc;
+                    vbest_soln = vsoln[ri];
+                    c_ell = cmin_soln + sqrt_u32(dist2(xg, nodes_g[vbest_soln]));
+                    __syncthreads();
+                }
+            }
+            pend_valid = false;  // barriers followed the insertion: node j and its cost are visible to every wave
+        } else {
+            pend = xq;
+            pend_cost = cbest;
+            pend_valid = true;
+        }
         j++;
         STAMP(4);
     }
@@ -726,6 +858,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         D->sum_near = sum_near;
         D->sum_cells_cand = sum_cells_cand;
         D->n_los_cand = n_los_cand;
+        D->n_rewired = n_rewired;
+        D->n_propagated = n_propagated;
 #ifdef RRT_STAMPS
         for (int k = 0; k < 6; ++k) D->cyc[k] = cyc[k];
 #endif
@@ -755,6 +889,11 @@ __global__ void rrt_init_kernel(BatchView bv) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         bv.vcost[(size_t)q * bv.node_stride] = 0.0;
         bv.parent[(size_t)q * bv.node_stride] = -1;
+        if (bv.kid_first) {
+            bv.kid_first[(size_t)q * bv.node_stride] = -1;
+            bv.kid_next[(size_t)q * bv.node_stride] = -1;
+            bv.kid_prev[(size_t)q * bv.node_stride] = -1;
+        }
     }
 }
 

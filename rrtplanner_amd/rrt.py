@@ -266,7 +266,7 @@ class RRT(object):
             self._grid_dirty = False
         return self._ctx
 
-    def _run(self, alg: int, xstart, xgoal, r_rewire=None, r_goal=None, logs=False):
+    def _run(self, alg: int, xstart, xgoal, r_rewire=None, r_goal=None, logs=False, rewire=False):
         """Drive one query through the C ABI.  Returns the ResultArrays (+ ellipse log inputs)."""
         if self._custom_cost:
             raise NotImplementedError(
@@ -300,7 +300,8 @@ class RRT(object):
             goal_d2=hostprep.goal_threshold(r_goal) if r_goal is not None else 0,
             Cmat=Cm,
         )
-        rc, res = ctx.plan(query, n, logs=logs or alg == _ffi.ALG_INFORMED)
+        kw = {"rewire": True} if rewire else {}
+        rc, res = ctx.plan(query, n, logs=logs or alg == _ffi.ALG_INFORMED, **kw)
         if rc == _ffi.RRT_NEED_UNITBALL:
             # The tree reached the goal region at iteration i_switch: from there on the reference
             # draws two uniforms per iteration instead of one free-space index (rrt.py:695-700).
@@ -319,7 +320,7 @@ class RRT(object):
             raise IndexError(f"index {INT64_MIN} is out of bounds for axis 0 with size {W}")
         res.xs, res.xg, res.Cm = xs, xg, Cm
         self.last_stats = {k: getattr(res, k) for k in ("j", "i_switch", "sum_j", "sum_cells_nn", "sum_near",
-                                                          "sum_cells_cand", "n_los_cand")}
+                                                          "sum_cells_cand", "n_los_cand", "n_rewired", "n_propagated")}
         return res
 
     def _materialise(self, res) -> Tuple[nx.DiGraph, int]:
@@ -388,16 +389,29 @@ class RRTStandard(RRT):
         return self._plan(_ffi.ALG_STANDARD, xstart, xgoal)[1]
 
 
+def _rewire_mode(rewire) -> bool:
+    if rewire not in ("reference", "correct"):
+        raise ValueError('rewire must be "reference" (the reference\'s behaviour, default) or "correct"')
+    return rewire == "correct"
+
+
 class RRTStar(RRT):
     """RRT with choose-parent inside r_rewire (reference rrt.py:453-556; its rewire step never
-    fires with the default cost)."""
+    fires with the default cost).
 
-    def __init__(self, og: np.ndarray, n: int, r_rewire: float, costfn: callable = None, pbar=True, seed: int = 0):
+    ``rewire="correct"`` (not in the reference, default ``"reference"``) opts into a true RRT* rewire with cost propagation:
+    after an insertion every near vertex that gets cheaper through the new node and sees it is re-parented, and the costs
+    of its descendants are recomputed.  Trees then differ from the reference's on purpose; everything else (sampling,
+    acceptance, choose-parent, go2goal, the returned graph) is unchanged."""
+
+    def __init__(self, og: np.ndarray, n: int, r_rewire: float, costfn: callable = None, pbar=True, seed: int = 0, rewire: str = "reference"):
         super().__init__(og, n, costfn=costfn, pbar=pbar, seed=seed)
         self.r_rewire = r_rewire
+        self.rewire = rewire
+        _rewire_mode(rewire)
 
     def plan(self, xstart: np.ndarray, xgoal: np.ndarray):
-        return self._plan(_ffi.ALG_STAR, xstart, xgoal, r_rewire=self.r_rewire)[1]
+        return self._plan(_ffi.ALG_STAR, xstart, xgoal, r_rewire=self.r_rewire, rewire=_rewire_mode(self.rewire))[1]
 
 
 class RRTStarInformed(RRT):
@@ -405,14 +419,16 @@ class RRTStarInformed(RRT):
     (reference rrt.py:562-758)."""
 
     def __init__(self, og: np.ndarray, n: int, r_rewire: float, r_goal: float, costfn: callable = None,
-                 pbar: bool = True, seed: int = 0):
+                 pbar: bool = True, seed: int = 0, rewire: str = "reference"):
         super().__init__(og, n, costfn=costfn, pbar=pbar, seed=seed)
         self.r_rewire = r_rewire
         self.r_goal = r_goal
         self.ellipses = {}  # j -> (xcent, major axis, minor axis, angle in degrees), for plotting
+        self.rewire = rewire  # "correct": opt-in true rewire, see RRTStar
+        _rewire_mode(rewire)
 
     def plan(self, xstart: np.ndarray, xgoal: np.ndarray):
-        res, out = self._plan(_ffi.ALG_INFORMED, xstart, xgoal, r_rewire=self.r_rewire, r_goal=self.r_goal)
+        res, out = self._plan(_ffi.ALG_INFORMED, xstart, xgoal, r_rewire=self.r_rewire, r_goal=self.r_goal, rewire=_rewire_mode(self.rewire))
         self._record_ellipses(res)
         return out
 

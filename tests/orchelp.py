@@ -74,7 +74,8 @@ class OracleCtx:
         res.pts[:live] = r.pts[:live]
         res.vcost[:live] = r.vcost[:live]
         res.parent[:live] = r.parent[:live]
-        for k in ("j", "vgoal", "found", "i_switch", "rows", "sum_j", "sum_cells_nn", "sum_near", "sum_cells_cand"):
+        for k in ("j", "vgoal", "found", "i_switch", "rows", "sum_j", "sum_cells_nn", "sum_near", "sum_cells_cand", "n_rewired",
+                  "n_propagated"):
             setattr(res.c, k, int(getattr(r, k)))
         res.c.status = st
         if hasattr(res, "nearest_log"):
@@ -84,11 +85,12 @@ class OracleCtx:
             res.j_log[:] = r.jlog
         assert n == r.pts.shape[0] - 1
 
-    def plan(self, query, n, logs=False):
+    def plan(self, query, n, logs=False, rewire=False):
         f = query_fields(query)
+        f["rewire"] = rewire
         self._q = f
         st, r = oracle.plan(self.og8, n, f["alg"], f["xs"], f["xg"], f["samples"], r2_rewire=f["r2_rewire"],
-                            r_goal=goal_d2_to_r(f["goal_d2"]), Cmat=f["Cmat"])
+                            r_goal=goal_d2_to_r(f["goal_d2"]), Cmat=f["Cmat"], rewire=rewire)
         res = _ffi.ResultArrays(n, logs)
         self._fill(res, st, r)
         return st, res
@@ -96,7 +98,8 @@ class OracleCtx:
     def plan_resume(self, unitball, res):
         f = self._q
         st, r = oracle.plan(self.og8, f["n"], f["alg"], f["xs"], f["xg"], f["samples"], r2_rewire=f["r2_rewire"],
-                            r_goal=goal_d2_to_r(f["goal_d2"]), unitball=unitball, ub_offset=res.i_switch, Cmat=f["Cmat"])
+                            r_goal=goal_d2_to_r(f["goal_d2"]), unitball=unitball, ub_offset=res.i_switch, Cmat=f["Cmat"],
+                            rewire=f["rewire"])
         self._fill(res, st, r)
         return st
 

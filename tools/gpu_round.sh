@@ -1,0 +1,36 @@
+#!/bin/bash
+# One GPU-box session: the -m gpu suite, the bench lines and the rocprofv3 passes whose summaries go to profiles/.
+#   gpurun --timeout 1200 -- bash tools/gpu_round.sh [tests|bench|prof|pmc ...]
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/r02
+mkdir -p $O
+export TMPDIR=/tmp
+cd /tmp
+for what in "$@"; do
+case $what in
+tests)
+    (cd $R && python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1); echo "tests rc=$?"; tail -n 3 $O/gpu_tests.log ;;
+bench)
+    python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -n 2 $O/bench_default.err
+    RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29999 python3 $R/bench.py --no-cpu-baseline --no-batched > $O/bench_one_rank_comm.json 2> $O/bench_one_rank_comm.err; echo "bench(comm) rc=$?"
+    python3 $R/bench.py --config 3 --no-batched > $O/bench_config3.json 2> $O/bench_config3.err; echo "bench c3 rc=$?"
+    python3 $R/bench.py --config 4 --no-cpu-baseline > $O/bench_config4.json 2> $O/bench_config4.err; echo "bench c4 rc=$?"
+    python3 $R/bench.py --queries 8 --no-cpu-baseline --no-batched > $O/bench_config2_q8.json 2>/dev/null
+    python3 $R/bench.py --queries 256 --no-cpu-baseline --no-batched > $O/bench_config2_q256.json 2>/dev/null
+    for t in 1 2 4 8 16 32; do python3 $R/bench.py --team $t --no-cpu-baseline --no-batched > $O/bench_config2_team$t.json 2>/dev/null; done
+    for t in 1 2 4 8; do python3 $R/bench.py --config 4 --team $t --no-cpu-baseline > $O/bench_config4_team$t.json 2>/dev/null; done ;;
+prof)
+    for c in 2 3 4; do
+        rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline --no-batched > $O/prof_c$c.json 2> $O/prof_c$c.err
+        echo "prof c$c rc=$?"
+    done ;;
+pmc)
+    for spec in "2 1" "3 1" "4 64" "2 8" "2 256"; do
+        set -- $spec; c=$1; q=$2
+        for ctr in FETCH_SIZE WRITE_SIZE; do
+            rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_c${c}_q${q}_$ctr -- python3 $R/bench.py --config $c --queries $q --steps 2 --warmup 1 --no-cpu-baseline --no-batched > $O/pmc_c${c}_q${q}_$ctr.json 2> $O/pmc_c${c}_q${q}_$ctr.err
+            echo "pmc c$c q$q $ctr rc=$?"
+        done
+    done ;;
+esac
+done
