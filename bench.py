@@ -35,7 +35,13 @@ CONFIGS = {
     3: dict(name="Informed-RRT* 1024x1024 n=50000 r_rewire=64 r_goal=12", alg=2, grid=1024, n=50000, r_rewire=64, r_goal=12, queries=1),
     4: dict(name="batch of independent RRT* queries 1024x1024 n=20000 r_rewire=64 (64 per GPU)", alg=1, grid=1024, n=20000,
             r_rewire=64, r_goal=None, queries=64),
+    # BASELINE.json configs[4]: no reference code exists for it (README only) -> own semantics (include/rrt_dubins.h), own oracle
+    5: dict(name="Dubins-RRT* 2048x2048 n=100000 r_rewire=64 rho=8 64 headings (256 independent queries per GPU, one CU each)", alg=4, grid=2048,
+            n=100000, r_rewire=64, r_goal=None, queries=256, rho=8.0, nh=64, grid_seed=3),
 }
+
+DUBINS_F64_OPS = 1150  # f64 operations of one dub_shortest() (include/rrt_dubins.h: 3 sincos, 9 atan2 + 2 acos at ~60 each, 4 sqrt, 6 words), counted from the source
+F64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector f64 (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes(res):
@@ -97,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="2-4: BASELINE.json configs[1..3]; 5: configs[4] (Dubins-RRT*, no reference parity)")
     ap.add_argument("--queries", type=int, default=None, help="queries per GPU (default: the config's)")
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--team", type=int, default=None, choices=[1, 2, 4, 8, 16, 32, 64],
@@ -133,7 +139,7 @@ def main():
     Q, n, alg = cfg["queries"], cfg["n"], cfg["alg"]
 
     # ---- synthetic workload: seeded noise grid, start/goal in one free component ----
-    og = perlin_occupancygrid(cfg["grid"], cfg["grid"], thresh=0.33, seed=1)
+    og = perlin_occupancygrid(cfg["grid"], cfg["grid"], thresh=0.33, seed=cfg.get("grid_seed", 1))
     og8 = hostprep.og_nonzero(og)
     free = np.argwhere(og == 0)
     sg_rng = np.random.default_rng(7)
@@ -145,16 +151,24 @@ def main():
     if use_comm:
         multi.init_comm(ctx, rank, world)  # RCCL communicator (ncclCommInitRank), id handed over on local tmpfs
     ctx.set_grid(og8)
-    batch = _ffi.Batch(ctx, Q, n, team=args.team)
-    keep, rngs, states = [], [], []
+    dubins = alg >= _ffi.ALG_DUBINS
+    batch = _ffi.Batch(ctx, Q, n, team=args.team, dubins=dubins)
+    keep, rngs, states, dub_inputs = [], [], [], []
     for slot in range(Q):
         g = rank + world * slot
         xs, xg = pairs[g]
         rng = np.random.default_rng(g)  # planner seed = global query index
         states.append(rng.bit_generator.state)
         samples = hostprep.draw_free_samples(rng, free, n)
-        Cm = hostprep.rotation_to_world_frame(xs, xg) if alg == 2 else None
-        qu, k = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2, goal_d2=gd2, Cmat=Cm)
+        if dubins:  # poses: start / goal headings from the query index, sample headings from the planner's stream
+            heads = rng.integers(0, cfg["nh"], size=n)
+            ps, pg = (int(xs[0]), int(xs[1]), (7 * g) % cfg["nh"]), (int(xg[0]), int(xg[1]), (13 * g + 5) % cfg["nh"])
+            qu, k = _ffi.make_query(alg, n, ps, pg, samples, r2_rewire=r2, headings=heads, rho=cfg["rho"], nh=cfg["nh"])
+            if slot == 0:
+                dub_inputs = [ps, pg, samples, heads]
+        else:
+            Cm = hostprep.rotation_to_world_frame(xs, xg) if alg == 2 else None
+            qu, k = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2, goal_d2=gd2, Cmat=Cm)
         keep.append(k)
         rngs.append(rng)
         batch.set_query(slot, qu)
@@ -212,7 +226,7 @@ def main():
     iters_local = Q * n
     bytes_local = sum(algorithmic_bytes(r.c) for r in results)
     pairs_local = sum(r.c.sum_j for r in results)
-    bad = [r.c.status for r in results if r.c.status != 0]
+    bad = [r.c.status for r in results if r.c.status not in (0, _ffi.RRT_E_GOAL_UNREACHABLE if dubins else 0)]
     if use_comm:
         # sanity of the collective: every rank's slab must describe its own queries; this rank's own slab must come back unchanged
         own = batch.get_result(0)
@@ -261,8 +275,22 @@ def main():
                          "achieved_is": "algorithmic (model) bytes per second, not measured HBM traffic",
                          "inner": inner_roof(pairs_local, kern_avg_ms, team * Q)},
         }
+        if dubins:
+            # no reference parity for this workload (the reference has no Dubins code); the kernel is the one-sample-per-iteration
+            # kernel with Dubins edges, bound by f64 VALU work (fixed-order sin / atan2 polynomials), not by HBM
+            out["metric"] = "Dubins-RRT* nodes-expanded/s on 2048x2048 noise grid; achieved HBM GB/s (model)"
+            out["dtype"] = "int16x2 coordinates / u8 headings / f64 Dubins arc lengths and costs"
+            out["roofline"]["kernel"] = "rrt_expand_kernel<false, true>"
+            out["config"]["reference_parity"] = "none: the reference only advertises Dubins planners (README.md:12,18-19)"
+            ndub = sum(r.c.sum_near for r in results) + 2 * iters_local + sum(r.c.n_los_cand for r in results)  # priced entries, nearest (length + sweep), candidate sweeps
+            fl = ndub * DUBINS_F64_OPS / (kern_avg_ms * 1e-3) / 1e12
+            out["roofline"]["inner"] = {"bound": "valu-f64", "achieved": fl, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / F64_VALU_PEAK_TFLOPS,
+                                        "dubins_word_evaluations_per_launch": int(ndub), "f64_ops_per_evaluation": DUBINS_F64_OPS}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(og8, cfg, pairs[0], free, states[0], ub_cache.get(0), results[0])
+            if dubins:
+                out["cpu_baseline"] = cpu_baseline_dubins(og8, cfg, dub_inputs, results[0])
+            else:
+                out["cpu_baseline"] = cpu_baseline(og8, cfg, pairs[0], free, states[0], ub_cache.get(0), results[0])
         if world == 1 and args.config == 2 and not args.no_batched:
             out["batched"] = batched_leg(ctx, og, og8, free, _ffi, hostprep)
         if world == 1 and args.rewire_leg and alg >= 1:
@@ -320,6 +348,25 @@ def batched_leg(ctx, og, og8, free, _ffi, hostprep):
                          "traffic": measured_traffic(4, Q, n, cus, pipelined),
                          "achieved_is": "algorithmic (model) bytes per second, not measured HBM traffic",
                          "inner": inner_roof(sum(r.c.sum_j for r in res), kms / steps, cus * Q)}}
+
+
+def cpu_baseline_dubins(og8, cfg, inputs, dev0):
+    """The Dubins oracle (oracle/dubins_oracle.c, 1 thread) on query 0; its result must equal the device's."""
+    import oracle
+    from rrtplanner_amd import hostprep
+
+    ps, pg, samples, heads = inputs
+    n = cfg["n"]
+    t0 = time.perf_counter()
+    st, r = oracle.dubins_plan(og8, n, 1, ps, pg, samples, heads, r2_rewire=hostprep.radius_threshold(cfg["r_rewire"]), rho=cfg["rho"], nh=cfg["nh"], logs=False)
+    dt = time.perf_counter() - t0
+    got = (dev0.c.status, dev0.c.j, dev0.c.vgoal, dev0.c.found, dev0.c.sum_j, dev0.c.sum_cells_nn, dev0.c.sum_near)
+    want = (st, r.j, r.vgoal, r.found, r.sum_j, r.sum_cells_nn, r.sum_near)
+    if got != want:
+        raise SystemExit(f"bench: Dubins query 0: device result {got} differs from the CPU oracle {want}")
+    return {"value": (r.j - 1) / dt, "unit": "nodes/s", "cores": 1, "kind": "port",
+            "sample": f"query 0 of the same workload (n={n}), 1 repetition, {dt:.1f} s of one host core", "host_cores": os.cpu_count(),
+            "device_result_equals_oracle": True}
 
 
 def rewire_leg(ctx, og8, cfg, pair, free, state0, _ffi, hostprep):

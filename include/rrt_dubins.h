@@ -1,0 +1,277 @@
+/*
+ * rrt_dubins.h -- Dubins-vehicle geometry for the Dubins-RRT / Dubins-RRT* planners (BASELINE.json configs[4],
+ * SURVEY.md 8(f) row 3).
+ *
+ * NO REFERENCE PARITY: rland93/rrtplanner only advertises "Dubins Vehicle RRT / RRT(star) Planner" (README.md:12,18-19);
+ * no such module is in its tree.  The semantics are defined by this build:
+ *
+ *   state     (x, y, h): integer grid cell and one of `nh` discrete headings, theta = 2 pi h / nh
+ *   edge      the shortest of the six Dubins words LSL, LSR, RSL, RSR, RLR, LRL of turning radius rho (cells) from the
+ *             parent's pose to the child's pose; ties between words go to the first in that order
+ *   cost      vcost[parent] + rho * (t + p + q), the arc length of that path
+ *   collision the path is sampled every DUB_DS cells of arc length from its start (k * DUB_DS, k = 0, 1, ...) and at its
+ *             end pose; a sample occupies the cell round-half-up of its coordinates; the path is free iff every such cell
+ *             lies inside the grid and is free.  "cells read" = samples up to and including the first blocked one.
+ *
+ * Plain C, usable from HIP device code and from gcc.  The CPU oracle (oracle/dubins_oracle.c) and the HIP kernel include
+ * this one header on purpose: the planner's decisions compare path lengths, so "bit-exact tree" needs bit-identical
+ * arithmetic, and libm's and the device's sin / atan2 / acos are not that.  Everything here is built from + - * /, sqrt and
+ * floor in a fixed order (both sides compile with -ffp-contract=off: no fused multiply-add, no reassociation), so gcc on
+ * the host and hipcc on gfx950 produce the same bits.  What the oracle adds is its own sequential loop; the FORMULAS are
+ * checked separately against numpy / libm (tests/test_dubins.py: every reported word, integrated forward with numpy,
+ * ends in the goal pose; lengths agree with an independent implementation to 1e-9).
+ */
+#ifndef RRT_DUBINS_H
+#define RRT_DUBINS_H
+
+#include <math.h>
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define RRT_DUB_FN __host__ __device__ static inline
+#else
+#define RRT_DUB_FN static inline
+#endif
+
+#define DUB_PI 3.141592653589793
+#define DUB_TWOPI 6.283185307179586
+#define DUB_DS 0.5 /* arc-length step of the collision sweep, cells */
+
+enum { DUB_LSL = 0, DUB_LSR = 1, DUB_RSL = 2, DUB_RSR = 3, DUB_RLR = 4, DUB_LRL = 5, DUB_NONE = 6 };
+
+typedef struct {
+    double t, p, q; /* the three segment lengths in units of rho (angles for arcs) */
+    double len;     /* rho * (t + p + q), cells; +inf when no word applies (cannot happen for rho > 0) */
+    int32_t word;
+} dub_path_t;
+
+/* ---- elementary functions with a fixed operation order ------------------------------------------------------------ */
+RRT_DUB_FN double dub_mod2pi(double a) { return a - DUB_TWOPI * floor(a / DUB_TWOPI); }
+
+/* sin and cos of a (|a| up to a few hundred): quadrant by Cody-Waite reduction with a two-part pi/2, then the Taylor
+ * polynomials on [-pi/4, pi/4] (truncation below 1e-17). */
+RRT_DUB_FN void dub_sincos(double a, double *s, double *c) {
+    const double k = floor(a * 0.6366197723675814 + 0.5); /* 2 / pi */
+    const double r = (a - k * 1.5707963267341256) - k * 6.077100506506192e-11; /* pi/2 = hi + lo, hi has 33 significant bits */
+    const double z = r * r;
+    const double sp = r * (1.0 + z * (-1.0 / 6.0 + z * (1.0 / 120.0 + z * (-1.0 / 5040.0 + z * (1.0 / 362880.0 + z * (-1.0 / 39916800.0 +
+                      z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
+    const double cp = 1.0 + z * (-0.5 + z * (1.0 / 24.0 + z * (-1.0 / 720.0 + z * (1.0 / 40320.0 + z * (-1.0 / 3628800.0 + z * (1.0 / 479001600.0 +
+                      z * (-1.0 / 87178291200.0 + z * (1.0 / 20922789888000.0))))))));
+    const double kq = k - 4.0 * floor(k * 0.25); /* k mod 4 in {0, 1, 2, 3} */
+    if (kq == 0.0) {
+        *s = sp;
+        *c = cp;
+    } else if (kq == 1.0) {
+        *s = cp;
+        *c = -sp;
+    } else if (kq == 2.0) {
+        *s = -sp;
+        *c = -cp;
+    } else {
+        *s = -cp;
+        *c = sp;
+    }
+}
+
+/* atan of z in [0, 1]: one argument reduction at tan(pi/8), then the alternating series in w^2 (|w| <= 0.4143, 21 terms:
+ * truncation below 1e-17) */
+RRT_DUB_FN double dub_atan01(double z) {
+    double base = 0.0, w = z;
+    if (z > 0.41421356237309503) {
+        w = (z - 1.0) / (z + 1.0);
+        base = 0.7853981633974483;
+    }
+    const double u = w * w;
+    double acc = 1.0 / 41.0;
+    acc = 1.0 / 39.0 - u * acc;
+    acc = 1.0 / 37.0 - u * acc;
+    acc = 1.0 / 35.0 - u * acc;
+    acc = 1.0 / 33.0 - u * acc;
+    acc = 1.0 / 31.0 - u * acc;
+    acc = 1.0 / 29.0 - u * acc;
+    acc = 1.0 / 27.0 - u * acc;
+    acc = 1.0 / 25.0 - u * acc;
+    acc = 1.0 / 23.0 - u * acc;
+    acc = 1.0 / 21.0 - u * acc;
+    acc = 1.0 / 19.0 - u * acc;
+    acc = 1.0 / 17.0 - u * acc;
+    acc = 1.0 / 15.0 - u * acc;
+    acc = 1.0 / 13.0 - u * acc;
+    acc = 1.0 / 11.0 - u * acc;
+    acc = 1.0 / 9.0 - u * acc;
+    acc = 1.0 / 7.0 - u * acc;
+    acc = 1.0 / 5.0 - u * acc;
+    acc = 1.0 / 3.0 - u * acc;
+    acc = 1.0 - u * acc;
+    return base + w * acc;
+}
+
+/* atan2(y, x) in (-pi, pi]; atan2(0, 0) = 0 */
+RRT_DUB_FN double dub_atan2(double y, double x) {
+    const double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
+    if (ax == 0.0 && ay == 0.0) return 0.0;
+    double a = (ay <= ax) ? dub_atan01(ay / ax) : 1.5707963267948966 - dub_atan01(ax / ay);
+    if (x < 0.0) a = DUB_PI - a;
+    return y < 0.0 ? -a : a;
+}
+
+/* acos(x) for |x| <= 1 */
+RRT_DUB_FN double dub_acos(double x) { return dub_atan2(sqrt((1.0 - x) * (1.0 + x)), x); }
+
+/* heading index -> angle */
+RRT_DUB_FN double dub_heading(int32_t h, int32_t nh) { return DUB_TWOPI * (double)h / (double)nh; }
+
+/* ---- the shortest Dubins word from pose 0 to pose 1 ------------------------------------------------------------------ */
+RRT_DUB_FN void dub_take(dub_path_t *best, int32_t word, double t, double p, double q) {
+    const double sum = t + p + q;
+    if (sum < best->len) { /* strict: an equal sum keeps the earlier word */
+        best->len = sum;
+        best->t = t;
+        best->p = p;
+        best->q = q;
+        best->word = word;
+    }
+}
+
+RRT_DUB_FN dub_path_t dub_shortest(double x0, double y0, double th0, double x1, double y1, double th1, double rho) {
+    const double dx = x1 - x0, dy = y1 - y0;
+    const double d = sqrt(dx * dx + dy * dy) / rho;
+    const double theta = dub_mod2pi(dub_atan2(dy, dx));
+    const double alpha = dub_mod2pi(th0 - theta), beta = dub_mod2pi(th1 - theta);
+    double sa, ca, sb, cb, sab, cab;
+    dub_sincos(alpha, &sa, &ca);
+    dub_sincos(beta, &sb, &cb);
+    dub_sincos(alpha - beta, &sab, &cab);
+    (void)sab;
+    const double dsq = d * d;
+    dub_path_t best;
+    best.t = best.p = best.q = 0.0;
+    best.len = HUGE_VAL;
+    best.word = DUB_NONE;
+    { /* LSL */
+        const double psq = 2.0 + dsq - 2.0 * cab + 2.0 * d * (sa - sb);
+        if (psq >= 0.0) {
+            const double tmp = dub_atan2(cb - ca, d + sa - sb);
+            dub_take(&best, DUB_LSL, dub_mod2pi(tmp - alpha), sqrt(psq), dub_mod2pi(beta - tmp));
+        }
+    }
+    { /* LSR */
+        const double psq = -2.0 + dsq + 2.0 * cab + 2.0 * d * (sa + sb);
+        if (psq >= 0.0) {
+            const double p = sqrt(psq);
+            const double tmp = dub_atan2(-ca - cb, d + sa + sb) - dub_atan2(-2.0, p);
+            dub_take(&best, DUB_LSR, dub_mod2pi(tmp - alpha), p, dub_mod2pi(tmp - dub_mod2pi(beta)));
+        }
+    }
+    { /* RSL */
+        const double psq = -2.0 + dsq + 2.0 * cab - 2.0 * d * (sa + sb);
+        if (psq >= 0.0) {
+            const double p = sqrt(psq);
+            const double tmp = dub_atan2(ca + cb, d - sa - sb) - dub_atan2(2.0, p);
+            dub_take(&best, DUB_RSL, dub_mod2pi(alpha - tmp), p, dub_mod2pi(beta - tmp));
+        }
+    }
+    { /* RSR */
+        const double psq = 2.0 + dsq - 2.0 * cab + 2.0 * d * (sb - sa);
+        if (psq >= 0.0) {
+            const double tmp = dub_atan2(ca - cb, d - sa + sb);
+            dub_take(&best, DUB_RSR, dub_mod2pi(alpha - tmp), sqrt(psq), dub_mod2pi(tmp - beta));
+        }
+    }
+    { /* RLR */
+        const double tmp = (6.0 - dsq + 2.0 * cab + 2.0 * d * (sa - sb)) / 8.0;
+        if (tmp <= 1.0 && tmp >= -1.0) {
+            const double phi = dub_atan2(ca - cb, d - sa + sb);
+            const double p = dub_mod2pi(DUB_TWOPI - dub_acos(tmp));
+            const double t = dub_mod2pi(alpha - phi + dub_mod2pi(p / 2.0));
+            dub_take(&best, DUB_RLR, t, p, dub_mod2pi(alpha - beta - t + dub_mod2pi(p)));
+        }
+    }
+    { /* LRL */
+        const double tmp = (6.0 - dsq + 2.0 * cab + 2.0 * d * (sb - sa)) / 8.0;
+        if (tmp <= 1.0 && tmp >= -1.0) {
+            const double phi = dub_atan2(ca - cb, d + sa - sb);
+            const double p = dub_mod2pi(DUB_TWOPI - dub_acos(tmp));
+            const double t = dub_mod2pi(-alpha - phi + p / 2.0);
+            dub_take(&best, DUB_LRL, t, p, dub_mod2pi(dub_mod2pi(beta) - alpha - t + dub_mod2pi(p)));
+        }
+    }
+    best.len = best.len * rho; /* (t + p + q) * rho; stays +inf when no word applied */
+    return best;
+}
+
+/* ---- points of a path ---------------------------------------------------------------------------------------------- */
+/* segment kinds of the words: +1 left arc, -1 right arc, 0 straight */
+RRT_DUB_FN int32_t dub_seg_kind(int32_t word, int32_t k) {
+    /* (kind + 1) in two bits per entry, entry 3 * word + k:  LSL 1,0,1  LSR 1,0,-1  RSL -1,0,1  RSR -1,0,-1  RLR -1,1,-1  LRL 1,-1,1 */
+    return (int32_t)((0x8881241a6ull >> (2 * (3 * word + k))) & 3ull) - 1;
+}
+
+/* advance the normalised pose (x, y, th) (unit turning radius) by tau along a segment of the given kind */
+RRT_DUB_FN void dub_advance(double x, double y, double th, int32_t kind, double tau, double *ox, double *oy, double *oth) {
+    double s0, c0;
+    dub_sincos(th, &s0, &c0);
+    if (kind == 0) {
+        *ox = x + c0 * tau;
+        *oy = y + s0 * tau;
+        *oth = th;
+    } else if (kind > 0) {
+        double s1, c1;
+        dub_sincos(th + tau, &s1, &c1);
+        *ox = x + (s1 - s0);
+        *oy = y - (c1 - c0);
+        *oth = th + tau;
+    } else {
+        double s1, c1;
+        dub_sincos(th - tau, &s1, &c1);
+        *ox = x - (s1 - s0);
+        *oy = y + (c1 - c0);
+        *oth = th - tau;
+    }
+}
+
+/* the sweep of one path, prepared once per path: the poses at the two junctions (normalised, relative to the start) */
+typedef struct {
+    double x0, y0, th0, rho;
+    double t, p, q;
+    double x1, y1, th1; /* pose after the first segment */
+    double x2, y2, th2; /* pose after the second segment */
+    int32_t k0, k1, k2; /* segment kinds */
+    int32_t nsamples;   /* samples at k * DUB_DS, k = 0 .. nsamples - 1 (the end pose is one more, tested as the goal cell) */
+} dub_sweep_t;
+
+RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const dub_path_t *path, double rho) {
+    dub_sweep_t s;
+    s.x0 = x0;
+    s.y0 = y0;
+    s.th0 = th0;
+    s.rho = rho;
+    s.t = path->t;
+    s.p = path->p;
+    s.q = path->q;
+    s.k0 = dub_seg_kind(path->word, 0);
+    s.k1 = dub_seg_kind(path->word, 1);
+    s.k2 = dub_seg_kind(path->word, 2);
+    dub_advance(0.0, 0.0, th0, s.k0, s.t, &s.x1, &s.y1, &s.th1);
+    dub_advance(s.x1, s.y1, s.th1, s.k1, s.p, &s.x2, &s.y2, &s.th2);
+    s.nsamples = (int32_t)floor(path->len / DUB_DS) + 1;
+    return s;
+}
+
+/* grid cell of sample k (arc length k * DUB_DS from the start) */
+RRT_DUB_FN void dub_sweep_cell(const dub_sweep_t *s, int32_t k, int32_t *cx, int32_t *cy) {
+    const double tau = ((double)k * DUB_DS) / s->rho; /* normalised arc length */
+    double x, y, th;
+    if (tau < s->t)
+        dub_advance(0.0, 0.0, s->th0, s->k0, tau, &x, &y, &th);
+    else if (tau < s->t + s->p)
+        dub_advance(s->x1, s->y1, s->th1, s->k1, tau - s->t, &x, &y, &th);
+    else
+        dub_advance(s->x2, s->y2, s->th2, s->k2, tau - (s->t + s->p), &x, &y, &th);
+    (void)th;
+    *cx = (int32_t)floor(s->x0 + x * s->rho + 0.5);
+    *cy = (int32_t)floor(s->y0 + y * s->rho + 0.5);
+}
+
+#endif /* RRT_DUBINS_H */

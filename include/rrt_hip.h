@@ -33,6 +33,12 @@ extern "C" {
 #define RRT_ALG_STANDARD 0 /* RRTStandard.plan     rrt.py:386 */
 #define RRT_ALG_STAR 1     /* RRTStar.plan         rrt.py:466 */
 #define RRT_ALG_INFORMED 2 /* RRTStarInformed.plan rrt.py:653 */
+/* Dubins-vehicle planners (BASELINE.json configs[4]).  The reference only advertises them (README.md:12,18-19) and ships no
+ * module: NO REFERENCE PARITY, semantics defined in include/rrt_dubins.h (state = cell + discrete heading, edge = shortest
+ * Dubins word of turning radius rho, cost = its arc length, collision = its sampled sweep; nearest / within / accept /
+ * choose-parent exactly as rrt.py:418-437 / :498-548).  Need a batch created with RRT_FLAG_DUBINS. */
+#define RRT_ALG_DUBINS 3      /* parent = nearest */
+#define RRT_ALG_DUBINS_STAR 4 /* choose parent within r_rewire */
 
 #define RRT_FLAG_LOGS 1u   /* keep per-iteration logs (nearest, accept, ellipse cost, j) on the device */
 #define RRT_FLAG_SERIAL 2u /* use the one-sample-per-iteration kernel instead of the 16-sample block kernel */
@@ -45,6 +51,8 @@ extern "C" {
 #define RRT_FLAG_REWIRE 32u /* opt-in TRUE RRT* rewire with cost propagation -- NOT the reference's behaviour: its
                               rewire step never fires (rrt.py:532-536 prices the rewire with vcosts[vn] + d, never below vcosts[vn]).
                               Semantics: oracle/rrt_oracle.c; runs on the one-sample-per-iteration kernel.  Default off. */
+#define RRT_FLAG_DUBINS 64u /* the batch runs Dubins queries (RRT_ALG_DUBINS / RRT_ALG_DUBINS_STAR) only: one-sample-per-iteration kernel
+                              with per-node headings.  rrt_plan sets it by itself for such a query. */
 #define RRT_FLAG_TEAM_MAX(g) ((uint32_t)(g) << 8) /* cap the team size at g CUs per query (g = 2, 4, ... 64; 0 = no cap) */
 
 typedef struct rrt_ctx rrt_ctx;
@@ -61,6 +69,12 @@ typedef struct rrt_query {
     int64_t goal_d2;        /* smallest integer G with (r2norm(d) < r_goal) <=> (d2 < G)      (rrt.py:744) */
     const int32_t *samples; /* host (n,2): free[rand_gen.choice(F)] for iteration i (rrt.py:240) */
     double C[4];            /* Informed: rotation_to_world_frame(xstart,xgoal), row-major (rrt.py:601-613) */
+    /* Dubins planners only (ignored otherwise) */
+    const int32_t *headings; /* host (n): heading index of sample i, 0 <= h < nh */
+    double rho;              /* turning radius in cells, > 0 */
+    int32_t nh;              /* number of discrete headings, 1 .. 256 */
+    int32_t hs, hg;          /* heading index of the start / goal pose */
+    int32_t pad_;
 } rrt_query;
 
 /* Result of one query: the arrays plan() hands to build_graph (rrt.py:334-369).
@@ -87,6 +101,7 @@ typedef struct rrt_result {
     int64_t n_los_cand;
     int64_t n_rewired;    /* RRT_FLAG_REWIRE: nodes re-parented / descendant costs recomputed (0 otherwise: rrt.py:536 is never true) */
     int64_t n_propagated;
+    int32_t *head;        /* Dubins planners: (n+1) heading index of every node; NULL to skip */
 } rrt_result;
 
 /* ---- context / grid -------------------------------------------------------------- */

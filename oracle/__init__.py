@@ -20,8 +20,9 @@ ORC_E_GOAL_UNREACHABLE = -2
 
 def build(force: bool = False) -> str:
     """Compile rrt_oracle.c -> liboracle.so with gcc (in-tree, git-ignored)."""
-    src = os.path.join(_HERE, "rrt_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "rrt_oracle.c"), os.path.join(_HERE, "dubins_oracle.c"),
+            os.path.join(os.path.dirname(_HERE), "include", "rrt_dubins.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -150,5 +151,90 @@ def plan(og8, n, alg, xs, xg, samples, r2_rewire=0, r_goal=0.0, unitball=None, u
     status = lib().orc_plan(C.byref(p))
     for k in ("j", "vgoal", "found", "i_switch", "rows", "sum_j", "sum_cells_nn", "sum_near", "sum_cells_cand",
               "n_rewired", "n_propagated"):
+        setattr(r, k, getattr(p, k))
+    return status, r
+
+
+# ---------------------------------------------------------------------------------------------- Dubins (no reference parity)
+class _DubPlan(C.Structure):
+    _fields_ = [
+        ("star", C.c_int32), ("n", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+        ("og", C.c_void_p),
+        ("xs", C.c_int32 * 3), ("xg", C.c_int32 * 3),
+        ("r2_rewire", C.c_int64), ("rho", C.c_double), ("nh", C.c_int32), ("pad_", C.c_int32),
+        ("samples", C.c_void_p), ("headings", C.c_void_p),
+        ("pts", C.c_void_p), ("head", C.c_void_p), ("vcost", C.c_void_p), ("parent", C.c_void_p),
+        ("nearest_log", C.c_void_p), ("accept_log", C.c_void_p),
+        ("j", C.c_int32), ("vgoal", C.c_int32), ("found", C.c_int32), ("rows", C.c_int32),
+        ("sum_j", C.c_int64), ("sum_cells_nn", C.c_int64), ("sum_near", C.c_int64), ("sum_cells_cand", C.c_int64),
+        ("n_dubins", C.c_int64),
+    ]
+
+
+def _dub_lib():
+    L = lib()
+    if not getattr(L, "_dub_bound", False):
+        L.orc_dubins_plan.argtypes = [C.POINTER(_DubPlan)]
+        L.orc_dubins_plan.restype = C.c_int
+        L.orc_dub_shortest.argtypes = [C.c_double] * 7 + [C.c_void_p]
+        L.orc_dub_shortest.restype = None
+        L.orc_dub_sweep_cells.argtypes = [C.c_double] * 7 + [C.c_void_p, C.c_int32]
+        L.orc_dub_sweep_cells.restype = C.c_int32
+        L.orc_dub_sincos.argtypes = [C.c_double, C.c_void_p]
+        L.orc_dub_sincos.restype = None
+        L.orc_dub_atan2.argtypes = [C.c_double, C.c_double]
+        L.orc_dub_atan2.restype = C.c_double
+        L._dub_bound = True
+    return L
+
+
+def dub_shortest(x0, y0, th0, x1, y1, th1, rho):
+    """(t, p, q, length, word) of include/rrt_dubins.h's shortest word."""
+    out = np.zeros(5)
+    _dub_lib().orc_dub_shortest(float(x0), float(y0), float(th0), float(x1), float(y1), float(th1), float(rho), out.ctypes.data)
+    return out[0], out[1], out[2], out[3], int(out[4])
+
+
+def dub_sweep_cells(x0, y0, th0, x1, y1, th1, rho, cap=100000):
+    out = np.zeros((cap, 2), dtype=np.int32)
+    m = _dub_lib().orc_dub_sweep_cells(float(x0), float(y0), float(th0), float(x1), float(y1), float(th1), float(rho), out.ctypes.data, cap)
+    return out[:m].copy()
+
+
+def dub_sincos(a):
+    out = np.zeros(2)
+    _dub_lib().orc_dub_sincos(float(a), out.ctypes.data)
+    return out[0], out[1]
+
+
+def dub_atan2(y, x):
+    return _dub_lib().orc_dub_atan2(float(y), float(x))
+
+
+def dubins_plan(og8, n, star, xs, xg, samples, headings, r2_rewire=0, rho=8.0, nh=64, logs=True):
+    """Run orc_dubins_plan once: xs / xg are (x, y, heading index).  Returns (status, PlanResult)."""
+    og8 = np.ascontiguousarray(og8, dtype=np.uint8)
+    samples = np.ascontiguousarray(samples, dtype=np.int32)
+    headings = np.ascontiguousarray(headings, dtype=np.int32)
+    assert samples.shape == (n, 2) and headings.shape == (n,)
+    p = _DubPlan()
+    p.star, p.n, p.W, p.H = int(bool(star)), n, og8.shape[0], og8.shape[1]
+    p.og = og8.ctypes.data
+    for k in range(3):
+        p.xs[k], p.xg[k] = int(xs[k]), int(xg[k])
+    p.r2_rewire, p.rho, p.nh = int(r2_rewire), float(rho), int(nh)
+    p.samples, p.headings = samples.ctypes.data, headings.ctypes.data
+    r = PlanResult()
+    r.pts = np.empty((n + 1, 2), dtype=np.int32)
+    r.head = np.empty(n + 1, dtype=np.int32)
+    r.vcost = np.empty(n + 1, dtype=np.float64)
+    r.parent = np.empty(n + 1, dtype=np.int32)
+    p.pts, p.head, p.vcost, p.parent = r.pts.ctypes.data, r.head.ctypes.data, r.vcost.ctypes.data, r.parent.ctypes.data
+    if logs:
+        r.nearest_log = np.full(n, -1, dtype=np.int32)
+        r.accept_log = np.zeros(n, dtype=np.uint8)
+        p.nearest_log, p.accept_log = r.nearest_log.ctypes.data, r.accept_log.ctypes.data
+    status = _dub_lib().orc_dubins_plan(C.byref(p))
+    for k in ("j", "vgoal", "found", "rows", "sum_j", "sum_cells_nn", "sum_near", "sum_cells_cand", "n_dubins"):
         setattr(r, k, getattr(p, k))
     return status, r

@@ -6,6 +6,8 @@ kernels for gfx950 behind the C ABI of include/rrt_hip.h.
 """
 from .rrt import RRT, RRTStandard, RRTStar, RRTStarInformed, r2norm, random_point_og
 from .oggen import perlin_occupancygrid
+from .dubins import RRTDubins, RRTStarDubins  # no reference counterpart (README only): see include/rrt_dubins.h
 
 __version__ = "0.1.0"
-__all__ = ["RRT", "RRTStandard", "RRTStar", "RRTStarInformed", "r2norm", "random_point_og", "perlin_occupancygrid"]
+__all__ = ["RRT", "RRTStandard", "RRTStar", "RRTStarInformed", "r2norm", "random_point_og", "perlin_occupancygrid",
+           "RRTDubins", "RRTStarDubins"]

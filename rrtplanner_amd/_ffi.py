@@ -23,20 +23,23 @@ RRT_E_UNSUPPORTED = -5
 RRT_E_COMM = -6
 
 ALG_STANDARD, ALG_STAR, ALG_INFORMED = 0, 1, 2
+ALG_DUBINS, ALG_DUBINS_STAR = 3, 4  # no reference counterpart (README only), see include/rrt_dubins.h
 FLAG_LOGS = 1
 FLAG_SERIAL = 2
 FLAG_NOTEAM = 4
 FLAG_TEAM_FAULT = 8
 FLAG_NOPIPE = 16
 FLAG_REWIRE = 32
+FLAG_DUBINS = 64
 
 
-def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=True, rewire=False):
+def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=True, rewire=False, dubins=False):
     """flags word of rrt_plan / rrt_batch_create.  team: None = as many CUs per query as fit (up to 64), 1 = one CU,
     2..64 = cap on the team size; pipe = False: teams of 8 and more do not pipeline super-blocks; team_fault = the
     fault-injection flag of the tests."""
     f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_TEAM_FAULT if team_fault else 0) | (0 if pipe else FLAG_NOPIPE)
     f |= FLAG_REWIRE if rewire else 0  # the opt-in true rewire (not the reference's behaviour)
+    f |= FLAG_DUBINS if dubins else 0
     if team == 1:
         f |= FLAG_NOTEAM
     elif team is not None:
@@ -71,6 +74,7 @@ class Query(C.Structure):
         ("r2_rewire", C.c_int64), ("goal_d2", C.c_int64),
         ("samples", C.c_void_p),
         ("C", C.c_double * 4),
+        ("headings", C.c_void_p), ("rho", C.c_double), ("nh", C.c_int32), ("hs", C.c_int32), ("hg", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -82,6 +86,7 @@ class Result(C.Structure):
         ("i_switch", C.c_int32), ("rows", C.c_int32),
         ("sum_j", C.c_int64), ("sum_cells_nn", C.c_int64), ("sum_near", C.c_int64), ("sum_cells_cand", C.c_int64),
         ("n_los_cand", C.c_int64), ("n_rewired", C.c_int64), ("n_propagated", C.c_int64),
+        ("head", C.c_void_p),
     ]
 
 
@@ -164,13 +169,17 @@ def comm_unique_id() -> bytes:
 class ResultArrays:
     """Host buffers for one query's result + the filled-in rrt_result."""
 
-    def __init__(self, n, logs=False):
+    def __init__(self, n, logs=False, headings=False):
         self.n = n
+        if headings:
+            self.head = np.zeros(n + 1, dtype=np.int32)
         self.pts = np.zeros((n + 1, 2), dtype=np.int32)
         self.vcost = np.zeros(n + 1, dtype=np.float64)
         self.parent = np.full(n + 1, -1, dtype=np.int32)
         self.c = Result()
         self.c.pts, self.c.vcost, self.c.parent = self.pts.ctypes.data, self.vcost.ctypes.data, self.parent.ctypes.data
+        if headings:
+            self.c.head = self.head.ctypes.data
         if logs:
             self.nearest_log = np.full(n, -1, dtype=np.int32)
             self.accept_log = np.zeros(n, dtype=np.uint8)
@@ -186,8 +195,9 @@ class ResultArrays:
         raise AttributeError(k)
 
 
-def make_query(alg, n, xs, xg, samples, r2_rewire=0, goal_d2=0, Cmat=None):
-    """Build an rrt_query; returns (Query, keepalive)."""
+def make_query(alg, n, xs, xg, samples, r2_rewire=0, goal_d2=0, Cmat=None, headings=None, rho=0.0, nh=0):
+    """Build an rrt_query; returns (Query, keepalive).  Dubins queries (alg 3 / 4): xs / xg are (x, y, heading index),
+    `headings` the heading index of every sample, rho the turning radius in cells, nh the number of headings."""
     s = np.ascontiguousarray(samples, dtype=np.int32)
     if s.shape != (n, 2):
         raise ValueError(f"samples must have shape ({n}, 2), got {s.shape}")
@@ -201,6 +211,12 @@ def make_query(alg, n, xs, xg, samples, r2_rewire=0, goal_d2=0, Cmat=None):
         cm = np.asarray(Cmat, dtype=np.float64).reshape(4)
         for k in range(4):
             q.C[k] = float(cm[k])
+    if headings is not None:
+        hd = np.ascontiguousarray(headings, dtype=np.int32)
+        if hd.shape != (n,):
+            raise ValueError(f"headings must have shape ({n},), got {hd.shape}")
+        q.headings, q.rho, q.nh, q.hs, q.hg = hd.ctypes.data, float(rho), int(nh), int(xs[2]), int(xg[2])
+        return q, (s, hd)
     return q, s
 
 
@@ -285,7 +301,7 @@ class Context:
 
     # ---- one-shot ----
     def plan(self, query, n, logs=False, serial=False, team=None, team_fault=False, pipe=True, rewire=False):
-        res = ResultArrays(n, logs)
+        res = ResultArrays(n, logs, headings=query.alg >= ALG_DUBINS)
         flags = kernel_flags(logs, serial, team, team_fault, pipe, rewire)
         rc = lib().rrt_plan(self._h, C.byref(query), flags, C.byref(res.c))
         _check(self._h, rc, ok=(RRT_OK, RRT_NEED_UNITBALL, RRT_E_GOAL_UNREACHABLE))
@@ -351,10 +367,10 @@ class Batch:
     """Q independent queries resident on the device (rrt_batch_*)."""
 
     def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False, team=None, team_fault: bool = False,
-                 pipe: bool = True, rewire: bool = False):
-        self.ctx, self.Q, self.n_cap, self.logs = ctx, int(Q), int(n_cap), logs
+                 pipe: bool = True, rewire: bool = False, dubins: bool = False):
+        self.ctx, self.Q, self.n_cap, self.logs, self.dubins = ctx, int(Q), int(n_cap), logs, dubins
         self._h = C.c_void_p()
-        flags = kernel_flags(logs, serial, team, team_fault, pipe, rewire)
+        flags = kernel_flags(logs, serial, team, team_fault, pipe, rewire, dubins)
         _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, flags, C.byref(self._h)))
         if not hasattr(ctx, "_batches"):
             ctx._batches = weakref.WeakSet()
@@ -407,7 +423,7 @@ class Batch:
         return ms.value
 
     def get_result(self, q, arrays=True):
-        res = ResultArrays(self._n[q], self.logs) if arrays else None
+        res = ResultArrays(self._n[q], self.logs, headings=self.dubins) if arrays else None
         if res is None:
             res = ResultArrays.__new__(ResultArrays)
             res.n = self._n[q]

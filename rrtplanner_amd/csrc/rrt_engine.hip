@@ -66,6 +66,9 @@ struct rrt_batch {
     int32_t *d_kids = nullptr;      // RRT_FLAG_REWIRE: [3][Q][node_stride] first child / next sibling / previous sibling
     uint32_t *d_frontier = nullptr; //                  [Q][2 * node_stride]
     int32_t *d_vsoln = nullptr;     //                  [Q][node_stride]
+    uint8_t *d_heading = nullptr;   // RRT_FLAG_DUBINS: [Q][node_stride] node headings
+    uint8_t *d_shead = nullptr;     //                  [Q][n_cap] sample headings
+    std::vector<uint8_t> stage8;
     uint4 *d_cellrec = nullptr;    // block kernel: near-set records, [Q][rec_stride]
     uint32_t *d_cellcnt = nullptr; // [Q][MAX_CELLS]
     int64_t rec_stride = 0;
@@ -345,7 +348,7 @@ extern "C" int rrt_batch_destroy(rrt_batch *b) {
     (void)hipStreamSynchronize(b->ctx->stream);
     void *ptrs[] = {b->d_desc,  b->d_samples,   b->d_slab,        b->d_bitmap, b->d_unitball,  b->d_cellrec,
                     b->d_spill, b->d_cbest_log, b->d_nearest_log, b->d_j_log,  b->d_accept_log, b->d_cellcnt,
-                    b->d_team,  b->d_kids,      b->d_frontier,    b->d_vsoln};
+                    b->d_team,  b->d_kids,      b->d_frontier,    b->d_vsoln,  b->d_heading,   b->d_shead};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -372,7 +375,12 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->node_stride = ((n_cap + 1 + CHUNK - 1) / CHUNK) * CHUNK;
     b->bitmap_words = (int32_t)(((size_t)ctx->W * ctx->H + 31) / 32);
     int chunks = (n_cap + 1 + CHUNK - 1) / CHUNK;
-    b->use_block = !(flags & (RRT_FLAG_SERIAL | RRT_FLAG_REWIRE));  // the opt-in rewire runs on the one-sample-per-iteration kernel
+    if ((flags & RRT_FLAG_DUBINS) && (flags & RRT_FLAG_REWIRE)) {
+        delete b;
+        return fail(ctx, RRT_E_UNSUPPORTED, "rrt_batch_create: the opt-in rewire is not available for the Dubins planners");
+    }
+    // the opt-in rewire and the Dubins planners run on the one-sample-per-iteration kernel
+    b->use_block = !(flags & (RRT_FLAG_SERIAL | RRT_FLAG_REWIRE | RRT_FLAG_DUBINS));
     if (b->use_block && !(flags & RRT_FLAG_NOTEAM)) {
         // the largest team (CUs per query) with every member of every team resident at once.  Blocks are dealt round-robin
         // to the 8 XCDs, so block = member * stride + query with stride = 0 (mod 8) keeps a team of up to 16 on one XCD (one
@@ -448,6 +456,10 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         ALLOC(b->d_frontier, 2 * q * b->node_stride * sizeof(uint32_t));
         ALLOC(b->d_vsoln, q * b->node_stride * sizeof(int32_t));
     }
+    if (flags & RRT_FLAG_DUBINS) {
+        ALLOC(b->d_heading, q * b->node_stride);
+        ALLOC(b->d_shead, q * n_cap);
+    }
     if (flags & RRT_FLAG_LOGS) {
         ALLOC(b->d_nearest_log, q * n_cap * sizeof(int32_t));
         ALLOC(b->d_accept_log, q * n_cap * sizeof(uint8_t));
@@ -490,7 +502,17 @@ extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu)
     if (!b || !qu) return fail(nullptr, RRT_E_ARG, "rrt_batch_set_query: NULL");
     rrt_ctx *ctx = b->ctx;
     if (q < 0 || q >= b->Q) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: q=%d of %d", q, b->Q);
-    if (qu->alg < 0 || qu->alg > 2) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: alg=%d", qu->alg);
+    if (qu->alg < 0 || qu->alg > RRT_ALG_DUBINS_STAR) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: alg=%d", qu->alg);
+    const bool dub = qu->alg >= RRT_ALG_DUBINS;
+    if (dub != ((b->flags & RRT_FLAG_DUBINS) != 0))
+        return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: alg=%d on a batch created %s RRT_FLAG_DUBINS", qu->alg, dub ? "without" : "with");
+    if (dub) {
+        if (!qu->headings || !(qu->rho > 0.0) || !std::isfinite(qu->rho) || qu->nh < 1 || qu->nh > 256 || qu->hs < 0 || qu->hs >= qu->nh ||
+            qu->hg < 0 || qu->hg >= qu->nh)
+            return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: Dubins query needs headings, rho > 0, 1 <= nh <= 256 and start / goal headings below nh");
+        for (int k = 0; k < qu->n; ++k)
+            if (qu->headings[k] < 0 || qu->headings[k] >= qu->nh) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: heading of sample %d outside [0, %d)", k, qu->nh);
+    }
     if (qu->n < 1 || qu->n > b->n_cap) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: n=%d, capacity %d", qu->n, b->n_cap);
     if (b->gridW != ctx->W || b->gridH != ctx->H)
         return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: grid changed shape since rrt_batch_create");
@@ -518,6 +540,15 @@ extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu)
     d.r2_rewire = (uint32_t)(qu->r2_rewire < 0 ? 0 : (qu->r2_rewire > cap ? cap : qu->r2_rewire));
     d.goal_d2 = (uint32_t)(qu->goal_d2 < 0 ? 0 : (qu->goal_d2 > cap ? cap : qu->goal_d2));
     for (int k = 0; k < 4; ++k) d.C[k] = qu->C[k];
+    if (dub) {
+        d.rho = qu->rho;
+        d.nh = qu->nh;
+        d.hs = qu->hs;
+        d.hg = qu->hg;
+        b->stage8.resize((size_t)qu->n);
+        for (int k = 0; k < qu->n; ++k) b->stage8[(size_t)k] = (uint8_t)qu->headings[k];
+        HIPCHK(ctx, hipMemcpyAsync(b->d_shead + (size_t)q * b->n_cap, b->stage8.data(), (size_t)qu->n, hipMemcpyHostToDevice, ctx->stream));
+    }
     cell_geometry(W, H, (int64_t)d.r2_rewire, b->n_cap, d.cell_shift, d.ncx, d.ncy, d.cell_cap);
     arm_desc(d);
     HIPCHK(ctx, hipMemcpyAsync(b->d_samples + (size_t)q * b->n_cap, b->stage.data(), (size_t)qu->n * sizeof(uint32_t),
@@ -594,6 +625,8 @@ static BatchView make_view(rrt_batch *b) {
         v.frontier = b->d_frontier;
         v.vsoln = b->d_vsoln;
     }
+    v.heading = b->d_heading;
+    v.sample_heading = b->d_shead;
     return v;
 }
 
@@ -683,15 +716,14 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     const size_t lds = expand_lds_bytes(b->lds_chunks);
     const size_t lds_static = (size_t)NWAVE * WCAP * sizeof(uint2) + 2 * NWAVE * (sizeof(Slot) + sizeof(BSlot));
     if ((int)(lds + lds_static) > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds + lds_static, ctx->max_lds);
-    const bool rw = (b->flags & RRT_FLAG_REWIRE) != 0;
-    HIPCHK(ctx, hipFuncSetAttribute(rw ? reinterpret_cast<const void *>(rrt_expand_kernel<true>) : reinterpret_cast<const void *>(rrt_expand_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    typedef void (*serial_kernel_fn)(BatchView);
+    const serial_kernel_fn kern = (b->flags & RRT_FLAG_DUBINS)  ? static_cast<serial_kernel_fn>(rrt_expand_kernel<false, true>)
+                                  : (b->flags & RRT_FLAG_REWIRE) ? static_cast<serial_kernel_fn>(rrt_expand_kernel<true, false>)
+                                                                 : static_cast<serial_kernel_fn>(rrt_expand_kernel<false, false>);
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
-    if (rw)
-        hipLaunchKernelGGL(rrt_expand_kernel<true>, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
-    else
-        hipLaunchKernelGGL(rrt_expand_kernel<false>, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
+    hipLaunchKernelGGL(kern, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     b->timed = true;
@@ -786,6 +818,12 @@ extern "C" int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out) {
     if (out->parent)
         HIPCHK(ctx, hipMemcpyAsync(out->parent, b->d_parent + (size_t)q * b->node_stride, (size_t)live * sizeof(int32_t),
                                    hipMemcpyDeviceToHost, ctx->stream));
+    if (out->head && b->d_heading) {
+        std::vector<uint8_t> tmp((size_t)live);
+        HIPCHK(ctx, hipMemcpyAsync(tmp.data(), b->d_heading + (size_t)q * b->node_stride, (size_t)live, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < live; ++k) out->head[k] = (int32_t)tmp[(size_t)k];
+    }
     const int ni = d.i;  // iterations executed so far
     if (b->flags & RRT_FLAG_LOGS) {
         const size_t o = (size_t)q * b->n_cap;
@@ -1029,6 +1067,7 @@ static int run_single(rrt_ctx *ctx, rrt_result *out) {
 extern "C" int rrt_plan(rrt_ctx *ctx, const rrt_query *query, uint32_t flags, rrt_result *out) {
     if (!ctx || !query || !out) return fail(ctx, RRT_E_ARG, "rrt_plan: NULL");
     if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_plan: call rrt_set_grid first");
+    if (query->alg >= RRT_ALG_DUBINS) flags |= RRT_FLAG_DUBINS;
     int rc = ensure_single(ctx, query->n, flags);
     if (rc != RRT_OK) return rc;
     rc = rrt_batch_set_query(ctx->single, 0, query);
@@ -1050,7 +1089,7 @@ extern "C" int rrt_plan_batch(rrt_ctx *ctx, int32_t Q, const rrt_query *queries,
     int32_t n_cap = 0;
     for (int q = 0; q < Q; ++q) n_cap = queries[q].n > n_cap ? queries[q].n : n_cap;
     rrt_batch *b = nullptr;
-    int rc = rrt_batch_create(ctx, Q, n_cap, 0, &b);
+    int rc = rrt_batch_create(ctx, Q, n_cap, queries[0].alg >= RRT_ALG_DUBINS ? RRT_FLAG_DUBINS : 0u, &b);
     if (rc != RRT_OK) return rc;
     for (int q = 0; q < Q && rc == RRT_OK; ++q) rc = rrt_batch_set_query(b, q, &queries[q]);
     if (rc == RRT_OK) rc = rrt_batch_launch(b);

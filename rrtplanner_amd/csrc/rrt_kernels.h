@@ -26,6 +26,7 @@
 #pragma once
 
 #include "rrt_device.h"
+#include "rrt_dubins_dev.h"
 
 namespace rrtdev {
 
@@ -45,6 +46,8 @@ struct QDesc {
     unsigned long long wcyc[32]; // diagnostic build: per-wave cycles in the block kernel's owner phase [0..15] and its LoS part [16..31]
     unsigned long long cyc[6];  // diagnostic build (-DRRT_STAMPS): wave-0 cycles in scan / pre-barrier / barrier / B+C / D / go2goal
     unsigned long long n_rewired, n_propagated;  // opt-in true rewire (RRT_FLAG_REWIRE): nodes re-parented, descendant costs recomputed
+    double rho;          // Dubins planners (alg 3 / 4): turning radius in cells, number of headings, start / goal heading index
+    int32_t nh, hs, hg, pad_;
 };
 
 struct BatchView {
@@ -73,6 +76,9 @@ struct BatchView {
     int32_t *kid_first, *kid_next, *kid_prev;  // [Q][node_stride] child lists: first child, next / previous sibling (-1 = none)
     uint32_t *frontier;                        // [Q][2 * node_stride] two propagation frontiers
     int32_t *vsoln;                            // [Q][node_stride] Informed: solution vertices in insertion order
+    // Dubins planners (RRT_FLAG_DUBINS; serial kernel only), null otherwise
+    uint8_t *heading;               // [Q][node_stride] heading index of every node
+    const uint8_t *sample_heading;  // [Q][n_cap]       heading index of sample i
 };
 
 constexpr int MAX_CELLS = 4096;  // cells per query (their fill counts live in LDS: 16 KiB)
@@ -183,12 +189,16 @@ constexpr int G2G_U = 4;      // nodes a wave tests per round
 
 // The nodes considered are kfirst + m * kstep, m < cnt (all of them: 0, 1, j; a team gives each member a stripe and takes the
 // minimum of the stripes' answers).
+template <bool DUB = false>
 __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const uint32_t *nodes_g, const double *vcost, int kfirst, int kstep,
                                               int cnt, uint32_t xg, uint32_t *order, RRT_LDS uint32_t *lds16k, BSlot *bslots, int t, int lane,
-                                              int wave, double &pc, uint32_t &pi) {
+                                              int wave, double &pc, uint32_t &pi, const uint8_t *heading = nullptr, int hg = 0, DubCfg dc = DubCfg{}) {
     RRT_LDS uint32_t *cursor = lds16k;          // [G2G_NB]
     RRT_LDS uint32_t *bend = lds16k + G2G_NB;   // [G2G_NB]
-    auto cost_of = [&](int k) -> double { return vcost[k] + sqrt_u32(dist2(nodes_g[k], xg)); };  // rrt.py:313-314
+    auto cost_of = [&](int k) -> double {  // rrt.py:313-314
+        if (DUB) return vcost[k] + dub_between_dev(nodes_g[k], heading[k], xg, hg, dc).len;
+        return vcost[k] + sqrt_u32(dist2(nodes_g[k], xg));
+    };
     // ---- cost range ----
     double cmin = f64_inf(), cmax = 0.0;
     for (int m = t; m < cnt; m += TPB) {
@@ -275,7 +285,14 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
             if (p < limit) {
                 const uint32_t k = order[p];
                 int cc = 0;
-                if (los_wave(og, H, nodes_g[k], xg, lane, cc)) {  // rrt.py:318
+                bool free_k;
+                if (DUB) {
+                    const dub_path_t pth = dub_between_dev(nodes_g[k], heading[k], xg, hg, dc);
+                    free_k = dub_sweep_wave(og, dc, nodes_g[k], heading[k], xg, pth, lane, cc);
+                } else {
+                    free_k = los_wave(og, H, nodes_g[k], xg, lane, cc);
+                }
+                if (free_k) {  // rrt.py:318
                     const double c = cost_of((int)k);
                     if (key_lt(c, k, bc, bi)) {
                         bc = c;
@@ -324,8 +341,12 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
 // the semantics): after an insertion every near-set entry vn with vcost[vnew] + dist < vcost[vn] and a free line of sight
 // vn -> xnew is re-parented to the new node, all decisions taken against the costs right after the insertion; then the costs
 // of the re-parented nodes' descendants are recomputed level by level over explicit child lists.
-template <bool RW>
+// DUB = true: the Dubins planners (alg 3 Dubins-RRT, 4 Dubins-RRT*; no reference counterpart, include/rrt_dubins.h): every
+// node and sample carries a heading, an edge is the shortest Dubins word between the two poses, its cost the word's arc
+// length, its collision test the sampled sweep of the word; nearest / within / accept / choose-parent order are unchanged.
+template <bool RW, bool DUB = false>
 __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
+    static_assert(!(RW && DUB), "the opt-in rewire is not built for the Dubins planners");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // node cache: lds_chunks * 16 KiB
     __shared__ __attribute__((aligned(16))) u32x2 wlist_lds[NWAVE * WCAP];
     __shared__ __attribute__((aligned(16))) Slot slots[2 * NWAVE];
@@ -342,7 +363,10 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
 
     // ---- per-query views ----
     const int n = D->n, alg = D->alg;
-    const bool star = alg >= 1, informed = alg == 2;
+    const bool star = DUB ? alg == 4 : alg >= 1, informed = !DUB && alg == 2;
+    uint8_t *heading = DUB ? bv.heading + (size_t)q * bv.node_stride : nullptr;
+    const uint8_t *shead = DUB ? bv.sample_heading + (size_t)q * bv.n_cap : nullptr;
+    const DubCfg dc{DUB ? D->rho : 1.0, DUB ? D->nh : 1, bv.W, bv.H};
     const uint32_t *samples = bv.samples + (size_t)q * bv.n_cap;
     uint32_t *nodes_g = bv.nodes + (size_t)q * bv.node_stride;
     const u32x4 *nodes_g4 = reinterpret_cast<const u32x4 *>(nodes_g);
@@ -398,12 +422,14 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
     uint32_t pend = 0;        // node j-1 when it was inserted by the previous iteration and may
     bool pend_valid = false;  // not be visible in LDS/HBM to the other waves yet
     double pend_cost = 0.0;
+    int pend_h = 0;
 
     // coordinates / cost of node v as seen by this iteration
     auto node_xy = [&](uint32_t v) -> uint32_t {
         if (pend_valid && (int)v == j - 1) return pend;
         return ((int)v < lds_nodes) ? nodes_lds[v] : nodes_g[v];
     };
+    auto node_h = [&](uint32_t v) -> int { return (pend_valid && (int)v == j - 1) ? pend_h : (int)heading[v]; };
     auto node_cost = [&](uint32_t v) -> double { return (pend_valid && (int)v == j - 1) ? pend_cost : vcost[v]; };
 
     uint32_t s_next = (i < n) ? samples[i] : 0;
@@ -412,7 +438,22 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         const int par = i & 1;
         // ---------------- sample (rrt.py:421 / :502 / :695-701) ----------------
         uint32_t xq = s_next;
+        const int hq = DUB ? (int)shead[i] : 0;
         if (i + 1 < n) s_next = samples[i + 1];
+        // an edge v -> sample: its length (the straight distance d2 is known from the scan) and its collision test
+        auto edge_len = [&](uint32_t v, uint32_t d2) -> double {
+            if (DUB) return dub_between_dev(node_xy(v), node_h(v), xq, hq, dc).len;
+            return sqrt_u32(d2);
+        };
+        auto edge_free = [&](uint32_t v, int &cc) -> bool {
+            if (DUB) {
+                const uint32_t a = node_xy(v);
+                const int ha = node_h(v);
+                const dub_path_t pth = dub_between_dev(a, ha, xq, hq, dc);
+                return dub_sweep_wave(og, dc, a, ha, xq, pth, lane, cc);
+            }
+            return los_wave(og, H, node_xy(v), xq, lane, cc);  // rrt.py:424 / :519
+        };
         double clog = __longlong_as_double(0x7ff8000000000000ll);
         if (informed && nsoln > 0) {
             if (i_switch == n) i_switch = i;
@@ -506,8 +547,9 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         double my_vc_nn = 0.0;
         if (ki != NONE) {
             my_vc_nn = node_cost(ki);
+            if (DUB) my_vc_nn += edge_len(ki, kd);  // the cost through the local nearest: the word's length is not a function of d2
             int cells = 0;
-            const bool ok = los_wave(og, H, node_xy(ki), xq, lane, cells);
+            const bool ok = edge_free(ki, cells);
             my_nn_los = (ok ? 0x80000000u : 0u) | (uint32_t)cells;
         }
         // (b) price this wave's near-set entries, keep them in registers; best and second best
@@ -525,18 +567,18 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                 if (c < wcnt && c < (uint32_t)WCAP) {
                     const u32x2 e = wl.list[c];
                     ei[s] = e.x;
-                    ec[s] = node_cost(e.x) + sqrt_u32(e.y);
+                    ec[s] = node_cost(e.x) + edge_len(e.x, e.y);
                     top.fold(ec[s], ei[s]);
                 }
             }
             for (uint32_t c = (uint32_t)WCAP + (uint32_t)lane; c < wcnt; c += 64) {  // overflow entries (huge radii)
                 const u32x2 e = wl.spill[c - WCAP];
-                top.fold(node_cost(e.x) + sqrt_u32(e.y), e.x);
+                top.fold(node_cost(e.x) + edge_len(e.x, e.y), e.x);
             }
             top.wave_reduce();
             if (top.i1 != NONE) {
                 int cc = 0;
-                const bool ok = los_wave(og, H, node_xy(top.i1), xq, lane, cc);  // rrt.py:519, speculative
+                const bool ok = edge_free(top.i1, cc);  // rrt.py:519, speculative
                 my_los1 = (ok ? 0x80000000u : 0u) | (uint32_t)cc;
             }
         }
@@ -597,7 +639,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
 
         // ---------------- C: choose parent (rrt.py:511-521) ----------------
         uint32_t vbest = vn;
-        double cbest = vc_near + sqrt_u32(d2n);
+        double cbest = DUB ? vc_near : vc_near + sqrt_u32(d2n);
         if (star) {
             const double cnear = cbest;
             sum_near += (unsigned long long)wave_sum_u32(s.wcnt);
@@ -628,7 +670,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                     if (ei[k] != NONE && ec[k] < cnear && !key_lt(ec[k], ei[k], lbc, lbi) && key_lt(ec[k], ei[k], pc, pi)) tt.fold(ec[k], ei[k]);
                 for (uint32_t c = (uint32_t)WCAP + (uint32_t)lane; c < wcnt; c += 64) {
                     const u32x2 e = wl.spill[c - WCAP];
-                    const double cn = node_cost(e.x) + sqrt_u32(e.y);
+                    const double cn = node_cost(e.x) + edge_len(e.x, e.y);
                     if (cn < cnear && !key_lt(cn, e.x, lbc, lbi) && key_lt(cn, e.x, pc, pi)) tt.fold(cn, e.x);
                 }
                 tt.wave_reduce();
@@ -641,7 +683,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                 bs.tested = 0;
                 if (tt.i1 != NONE) {
                     int cc = 0;
-                    const bool ok = los_wave(og, H, node_xy(tt.i1), xq, lane, cc);
+                    const bool ok = edge_free(tt.i1, cc);
                     if (ok) {
                         bs.pc = tt.c1;
                         bs.pi = tt.i1;
@@ -685,6 +727,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
             if (j < lds_nodes) nodes_lds[j] = xq;
             vcost[j] = cbest;
             parent[j] = (int32_t)vbest;
+            if (DUB) heading[j] = (uint8_t)hq;
             atomicOr(&bitmap[cell >> 5], 1u << (cell & 31));  // rrt.py:426
         }
         if (informed && dist2(xq, xg) < goal_d2) {  // rrt.py:744-745
@@ -809,6 +852,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         } else {
             pend = xq;
             pend_cost = cbest;
+            pend_h = hq;
             pend_valid = true;
         }
         j++;
@@ -827,7 +871,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         status = ST_DONE;
         double pc;
         uint32_t pi;
-        go2goal_phase(og, H, nodes_g, vcost, 0, 1, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)smem, bslots, t, lane, wave, pc, pi);
+        go2goal_phase<DUB>(og, H, nodes_g, vcost, 0, 1, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)smem, bslots, t, lane, wave, pc, pi,
+                           heading, DUB ? D->hg : 0, dc);
         if (pi != NONE) {
             found = 1;
             vgoal = j;  // rrt.py:319
@@ -835,6 +880,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                 nodes_g[j] = xg;
                 vcost[j] = pc;
                 parent[j] = (int32_t)pi;
+                if (DUB) heading[j] = (uint8_t)D->hg;
             }
         } else {
             if (j < n) status = ST_UNREACHABLE;  // the next argsort entry is a sentinel row (rrt.py:318 faults)
@@ -889,6 +935,7 @@ __global__ void rrt_init_kernel(BatchView bv) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         bv.vcost[(size_t)q * bv.node_stride] = 0.0;
         bv.parent[(size_t)q * bv.node_stride] = -1;
+        if (bv.heading) bv.heading[(size_t)q * bv.node_stride] = (uint8_t)D->hs;
         if (bv.kid_first) {
             bv.kid_first[(size_t)q * bv.node_stride] = -1;
             bv.kid_next[(size_t)q * bv.node_stride] = -1;

@@ -86,6 +86,8 @@ class OracleCtx:
         assert n == r.pts.shape[0] - 1
 
     def plan(self, query, n, logs=False, rewire=False):
+        if query.alg >= _ffi.ALG_DUBINS:
+            return self._plan_dubins(query, n, logs)
         f = query_fields(query)
         f["rewire"] = rewire
         self._q = f
@@ -93,6 +95,21 @@ class OracleCtx:
                             r_goal=goal_d2_to_r(f["goal_d2"]), Cmat=f["Cmat"], rewire=rewire)
         res = _ffi.ResultArrays(n, logs)
         self._fill(res, st, r)
+        return st, res
+
+    def _plan_dubins(self, query, n, logs):
+        samples = np.ctypeslib.as_array(C.cast(query.samples, C.POINTER(C.c_int32)), shape=(n, 2)).copy()
+        heads = np.ctypeslib.as_array(C.cast(query.headings, C.POINTER(C.c_int32)), shape=(n,)).copy()
+        st, r = oracle.dubins_plan(self.og8, n, query.alg == _ffi.ALG_DUBINS_STAR, (query.xs[0], query.xs[1], query.hs),
+                                   (query.xg[0], query.xg[1], query.hg), samples, heads, r2_rewire=query.r2_rewire, rho=query.rho, nh=query.nh)
+        res = _ffi.ResultArrays(n, logs, headings=True)
+        live = r.j + (1 if r.found else 0)
+        res.pts[:live], res.vcost[:live], res.parent[:live], res.head[:live] = r.pts[:live], r.vcost[:live], r.parent[:live], r.head[:live]
+        for k in ("j", "vgoal", "found", "rows", "sum_j", "sum_cells_nn", "sum_near", "sum_cells_cand"):
+            setattr(res.c, k, int(getattr(r, k)))
+        res.c.status = st
+        if logs:
+            res.nearest_log[:], res.accept_log[:] = r.nearest_log, r.accept_log
         return st, res
 
     def plan_resume(self, unitball, res):

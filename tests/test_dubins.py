@@ -1,0 +1,253 @@
+"""Dubins-vehicle RRT / RRT* (BASELINE.json configs[4]).  NO REFERENCE PARITY: the reference only advertises these planners
+(README.md:12,18-19), so three things are checked instead --
+  1. the geometry of include/rrt_dubins.h (fixed-order arithmetic shared by oracle and kernel) against numpy / libm: every
+     reported word, integrated forward, ends in the goal pose; lengths equal an independent numpy implementation
+     (rrtplanner_amd/dubins.py) and obey the symmetries of shortest Dubins paths;
+  2. the oracle's sequential loop (oracle/dubins_oracle.c) for the properties that define the planner;
+  3. the HIP kernel bit for bit against that oracle (GPU)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+import orchelp
+from rrtplanner_amd import _ffi, hostprep
+from rrtplanner_amd import dubins as dub
+from rrtplanner_amd.oggen import perlin_occupancygrid, random_connected_pair
+
+KIND = {0: (1, 0, 1), 1: (1, 0, -1), 2: (-1, 0, 1), 3: (-1, 0, -1), 4: (-1, 1, -1), 5: (1, -1, 1)}
+
+
+def _integrate(x, y, th, word, t, p, q, rho):
+    for kind, tau in zip(KIND[word], (t, p, q)):
+        if kind == 0:
+            x, y = x + rho * tau * math.cos(th), y + rho * tau * math.sin(th)
+        else:
+            x += kind * rho * (math.sin(th + kind * tau) - math.sin(th))
+            y -= kind * rho * (math.cos(th + kind * tau) - math.cos(th))
+            th += kind * tau
+    return x, y, th
+
+
+def test_elementary_functions_match_libm():
+    rng = np.random.default_rng(0)
+    for a in np.concatenate([rng.uniform(-60, 60, 4000), np.linspace(-7, 7, 701)]):
+        s, c = oracle.dub_sincos(a)
+        assert abs(s - math.sin(a)) < 4e-16 and abs(c - math.cos(a)) < 4e-16
+    for _ in range(4000):
+        y, x = rng.normal(size=2) * rng.choice([1e-3, 1, 1e3])
+        assert abs(oracle.dub_atan2(y, x) - math.atan2(y, x)) < 1e-15
+    for y, x in [(0, 1), (0, -1), (1, 0), (-1, 0), (0, 0), (1, 1), (-1, -1), (1e-300, 1), (-2.0, 0.0)]:
+        assert abs(oracle.dub_atan2(y, x) - math.atan2(y, x)) < 1e-15
+
+
+def test_every_word_reaches_the_goal_pose_and_lengths_are_symmetric():
+    rng = np.random.default_rng(1)
+    seen = set()
+    for _ in range(20000):
+        rho = float(rng.choice([1.0, 4.0, 8.0, 13.7]))
+        sc = float(rng.choice([0.5, 2, 6, 40])) * rho
+        x0, y0, x1, y1 = rng.uniform(-sc, sc, 4)
+        th0, th1 = rng.uniform(0, 2 * math.pi, 2)
+        t, p, q, L, w = oracle.dub_shortest(x0, y0, th0, x1, y1, th1, rho)
+        assert w < 6
+        seen.add(w)
+        xe, ye, the = _integrate(x0, y0, th0, w, t, p, q, rho)
+        assert max(abs(xe - x1), abs(ye - y1), abs(math.remainder(the - th1, 2 * math.pi))) < 1e-9
+        assert L >= math.hypot(x1 - x0, y1 - y0) - 1e-9 and abs(L - rho * (t + p + q)) < 1e-12 * max(1, L)
+        assert abs(L - oracle.dub_shortest(x1, y1, th1 + math.pi, x0, y0, th0 + math.pi, rho)[3]) < 1e-7 * max(1, L)  # driven backwards
+        assert abs(L - oracle.dub_shortest(x0, -y0, -th0, x1, -y1, -th1, rho)[3]) < 1e-7 * max(1, L)               # mirrored
+    assert seen == {0, 1, 2, 3, 4, 5}
+
+
+def test_header_agrees_with_the_independent_numpy_implementation():
+    rng = np.random.default_rng(2)
+    m = 5000
+    rho = 7.5
+    P = rng.uniform(-60, 60, size=(m, 4))
+    th = rng.integers(0, 64, size=(m, 2)) * (2 * math.pi / 64)
+    t, p, q, L, w = dub.dubins_shortest(P[:, 0], P[:, 1], th[:, 0], P[:, 2], P[:, 3], th[:, 1], rho)
+    for k in range(m):
+        t2, p2, q2, L2, w2 = oracle.dub_shortest(P[k, 0], P[k, 1], th[k, 0], P[k, 2], P[k, 3], th[k, 1], rho)
+        assert abs(L[k] - L2) < 1e-9 * max(1.0, L2)
+        if w[k] != w2:  # only when two words tie to rounding
+            assert abs(L[k] - L2) < 1e-9
+
+
+def test_sweep_cells_lie_on_the_numpy_polyline():
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        rho, nh = float(rng.choice([3.0, 8.0])), 64
+        a = (int(rng.integers(0, 200)), int(rng.integers(0, 200)), int(rng.integers(0, nh)))
+        b = (int(rng.integers(0, 200)), int(rng.integers(0, 200)), int(rng.integers(0, nh)))
+        cells = oracle.dub_sweep_cells(a[0], a[1], 2 * math.pi * a[2] / nh, b[0], b[1], 2 * math.pi * b[2] / nh, rho)
+        poly = dub.dubins_polyline(a, b, rho, nh, ds=0.5)
+        assert len(cells) == len(poly) - 1 or len(cells) == len(poly)  # the polyline appends the end point
+        pts = poly[:len(cells)]
+        off = np.abs(pts - cells)  # a sample lies in the cell it rounds to: within half a cell (+ rounding noise at the boundary)
+        assert np.all(off <= 0.5 + 1e-6)
+        assert cells[0].tolist() == [a[0], a[1]] and np.allclose(poly[-1], b[:2], atol=1e-8)
+
+
+def _dub_query(grid, n, seed, gseed=1):
+    og = perlin_occupancygrid(grid, grid, seed=gseed)
+    og8 = oracle.og_u8(og)
+    xs, xg = random_connected_pair(og, np.random.default_rng(11))
+    rng = np.random.default_rng(seed)
+    samples = hostprep.draw_free_samples(rng, np.argwhere(og8 == 0), n)
+    heads = rng.integers(0, 64, size=n)
+    return og, og8, (int(xs[0]), int(xs[1]), 5), (int(xg[0]), int(xg[1]), 20), samples, heads
+
+
+def _check_dubins_tree(og8, r, rho, nh, xs):
+    live = r.j + (1 if r.found else 0)
+    par, pts, hd = r.parent[:live].astype(np.int64), r.pts[:live].astype(np.int64), r.head[:live].astype(np.int64)
+    assert par[0] == -1 and np.all(par[1:] >= 0) and np.all(par[1:] < np.arange(1, live)) and (pts[0, 0], pts[0, 1], hd[0]) == tuple(xs)
+    assert np.all(og8[pts[:, 0], pts[:, 1]] == 0) and np.all((0 <= hd) & (hd < nh))
+    assert len({(a, b) for a, b in pts[:r.j].tolist()}) >= r.j - 1  # one node per cell (xstart may repeat once, rrt.py:425)
+    L = dub.dubins_shortest(pts[par[1:], 0], pts[par[1:], 1], 2 * math.pi * hd[par[1:]] / nh, pts[1:, 0], pts[1:, 1], 2 * math.pi * hd[1:] / nh, rho)[3]
+    assert np.allclose(r.vcost[1:live], r.vcost[par[1:]] + L, rtol=0, atol=1e-8)
+    for c in range(1, live, max(1, live // 300)):  # every edge's sweep is free
+        p = par[c]
+        cells = oracle.dub_sweep_cells(pts[p, 0], pts[p, 1], 2 * math.pi * hd[p] / nh, pts[c, 0], pts[c, 1], 2 * math.pi * hd[c] / nh, rho)
+        assert np.all((cells >= 0) & (cells < og8.shape[0])) and np.all(og8[cells[:, 0], cells[:, 1]] == 0)
+
+
+@pytest.mark.parametrize("star", [0, 1])
+def test_oracle_dubins_plan_properties(star):
+    og, og8, xs, xg, samples, heads = _dub_query(300, 4000, 0)
+    st, r = oracle.dubins_plan(og8, 4000, star, xs, xg, samples, heads, r2_rewire=hostprep.radius_threshold(40), rho=6.0, nh=64)
+    assert st == 0 and r.found and r.j > 1000
+    _check_dubins_tree(og8, r, 6.0, 64, xs)
+    st0, r0 = oracle.dubins_plan(og8, 4000, 0, xs, xg, samples, heads, rho=6.0, nh=64)
+    assert r.j == r0.j and np.array_equal(r.pts[:r.j], r0.pts[:r0.j])  # acceptance does not depend on choose-parent
+    if star:
+        assert np.all(r.vcost[:r.j] <= r0.vcost[:r0.j] + 1e-9) and r.vcost[:r.j].mean() < r0.vcost[:r0.j].mean()
+
+
+def test_planner_classes_on_the_oracle_stand_in():
+    og, og8, xs, xg, _, _ = _dub_query(160, 700, 0)
+    with pytest.raises(ValueError):
+        dub.RRTStarDubins(og, 10, 5, rho=0.0)
+    p = orchelp.use_oracle(dub.RRTStarDubins(og, 700, 30, rho=5.0, n_headings=32, pbar=False, seed=4))
+    with pytest.raises(ValueError):
+        p.plan(np.array([1, 2]), np.array(xg))  # not a pose
+    with pytest.raises(ValueError):
+        p.plan(np.array(xs), np.array([xg[0], xg[1], 32]))  # heading index outside [0, 32)
+    T, gv = p.plan(np.array(xs), np.array(xg))
+    assert T.number_of_nodes() == 701 and gv == p.last_stats["j"]
+    path = p.route2gv(T, gv)
+    assert path[0] == 0 and path[-1] == gv and T.nodes[gv]["heading"] == xg[2] and T.nodes[gv]["pt"].tolist() == list(xg[:2])
+    d = [T.edges[u, v]["dist"] for u, v in zip(path[:-1], path[1:])]
+    assert np.isclose(sum(d), T.edges[path[-2], path[-1]]["cost"], atol=1e-8)
+    poly = p.path_points(T, path, ds=0.5)
+    assert np.allclose(poly[0], xs[:2]) and np.allclose(poly[-1], xg[:2], atol=1e-7)
+    seg = np.hypot(*np.diff(poly, axis=0).T)
+    assert np.all(seg <= 0.5 + 1e-9) and np.isclose(seg.sum(), sum(d), rtol=2e-2)  # chords of arcs: slightly shorter than the arcs
+    cells = np.floor(poly + 0.5).astype(int)
+    assert np.all(og8[cells[:, 0], cells[:, 1]] == 0)
+    q = orchelp.use_oracle(dub.RRTDubins(og, 300, rho=5.0, n_headings=32, pbar=False, seed=4))
+    T2, g2 = q.plan(np.array(xs), np.array(xg))
+    assert T2.number_of_nodes() == 301
+    s = q.sample_all_free()
+    assert s.shape == (3,) and og[s[0], s[1]] == 0 and 0 <= s[2] < 32
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+def _device_vs_oracle_dubins(ctx, og8, star, n, xs, xg, samples, heads, rr, rho, nh=64):
+    r2 = hostprep.radius_threshold(rr) if star else 0
+    q, keep = _ffi.make_query(_ffi.ALG_DUBINS_STAR if star else _ffi.ALG_DUBINS, n, xs, xg, samples, r2_rewire=r2, headings=heads, rho=rho, nh=nh)
+    rc, res = ctx.plan(q, n, logs=True)
+    st, ro = oracle.dubins_plan(og8, n, star, xs, xg, samples, heads, r2_rewire=r2, rho=rho, nh=nh)
+    assert rc == st
+    live = ro.j + (1 if ro.found else 0)
+    assert (res.j, res.found, res.vgoal) == (ro.j, ro.found, ro.vgoal)
+    assert np.array_equal(res.nearest_log, ro.nearest_log) and np.array_equal(res.accept_log, ro.accept_log)
+    assert np.array_equal(res.pts[:live], ro.pts[:live]) and np.array_equal(res.head[:live], ro.head[:live])
+    assert np.array_equal(res.parent[:live], ro.parent[:live])
+    assert np.array_equal(res.vcost[:live], ro.vcost[:live])  # bit-exact: one arithmetic on both sides
+    assert res.sum_j == ro.sum_j and res.sum_cells_nn == ro.sum_cells_nn and res.sum_near == ro.sum_near
+    return res, ro
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("star,grid,n,rr,rho,seed", [
+    (0, 300, 4000, None, 6.0, 0), (1, 300, 4000, 40, 6.0, 0), (1, 1024, 20000, 64, 8.0, 1), (1, 64, 2500, 12, 2.0, 2),
+    (1, 200, 3000, 1e6, 4.0, 3), (0, 2048, 30000, None, 8.0, 5), (1, 2048, 30000, 64, 8.0, 5), (1, 128, 1500, 20, 25.0, 6)])
+def test_device_dubins_equals_the_oracle(gpu_ctx, star, grid, n, rr, rho, seed):
+    og, og8, xs, xg, samples, heads = _dub_query(grid, n, seed, gseed=3 if grid == 2048 else 1)
+    gpu_ctx.set_grid(og8)
+    res, ro = _device_vs_oracle_dubins(gpu_ctx, og8, star, n, xs, xg, samples, heads, rr, rho)
+    _check_dubins_tree(og8, res, rho, 64, xs)
+
+
+@pytest.mark.gpu
+def test_device_dubins_fuzz_small(gpu_ctx):
+    rng = np.random.default_rng(99)
+    for case in range(150):
+        w, h = int(rng.integers(8, 70)), int(rng.integers(8, 70))
+        og8 = (rng.uniform(size=(w, h)) < rng.choice([0.0, 0.1, 0.3])).astype(np.uint8)
+        free = np.argwhere(og8 == 0)
+        if free.shape[0] < 2:
+            continue
+        star = int(rng.integers(0, 2))
+        n = int(rng.choice([1, 2, 17, 64, 100, 300, 800]))
+        nh = int(rng.choice([1, 8, 64, 256]))
+        rho = float(rng.choice([0.5, 1.5, 4.0, 12.0]))
+        rr = float(rng.choice([2, 8, 20, 500]))
+        a, b = free[rng.integers(0, free.shape[0])], free[rng.integers(0, free.shape[0])]
+        xs, xg = (int(a[0]), int(a[1]), int(rng.integers(0, nh))), (int(b[0]), int(b[1]), int(rng.integers(0, nh)))
+        srng = np.random.default_rng(case)
+        samples = hostprep.draw_free_samples(srng, free, n)
+        heads = srng.integers(0, nh, size=n)
+        gpu_ctx.set_grid(og8)
+        try:
+            _device_vs_oracle_dubins(gpu_ctx, og8, star, n, xs, xg, samples, heads, rr, rho, nh)
+        except AssertionError as e:
+            raise AssertionError(f"dubins fuzz case {case}: {w}x{h} star {star} n {n} nh {nh} rho {rho} r {rr} xs {xs} xg {xg}") from e
+
+
+@pytest.mark.gpu
+def test_dubins_planner_class_and_batch_on_device(gpu_ctx):
+    og, og8, xs, xg, _, _ = _dub_query(400, 5000, 0)
+    p = dub.RRTStarDubins(og, 5000, 48, rho=6.0, pbar=False, seed=2)
+    try:
+        T, gv = p.plan(np.array(xs), np.array(xg))
+    except IndexError:
+        pytest.skip("goal pose unreachable in this draw")
+    o = orchelp.use_oracle(dub.RRTStarDubins(og, 5000, 48, rho=6.0, pbar=False, seed=2))
+    To, go = o.plan(np.array(xs), np.array(xg))
+    assert gv == go and list(T.edges) == list(To.edges)
+    assert [T.nodes[v]["heading"] for v in T.nodes] == [To.nodes[v]["heading"] for v in To.nodes]
+    assert [d["cost"] for _, _, d in T.edges(data=True)] == [d["cost"] for _, _, d in To.edges(data=True)]
+    # a batch of Dubins queries (one CU each), and the flag / algorithm mismatch is refused
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    Q, n = 6, 2500
+    b = _ffi.Batch(gpu_ctx, Q, n, dubins=True)
+    refs, keep = [], []
+    sg = np.random.default_rng(5)
+    for q in range(Q):
+        a, c = random_connected_pair(og, sg)
+        qs, qg = (int(a[0]), int(a[1]), q), (int(c[0]), int(c[1]), 3 * q)
+        rng = np.random.default_rng(q)
+        s = hostprep.draw_free_samples(rng, free, n)
+        hd = rng.integers(0, 64, size=n)
+        qu, k = _ffi.make_query(_ffi.ALG_DUBINS_STAR if q % 2 else _ffi.ALG_DUBINS, n, qs, qg, s, r2_rewire=hostprep.radius_threshold(30), headings=hd, rho=5.0, nh=64)
+        keep.append(k)
+        b.set_query(q, qu)
+        refs.append(oracle.dubins_plan(og8, n, q % 2, qs, qg, s, hd, r2_rewire=hostprep.radius_threshold(30), rho=5.0, nh=64, logs=False))
+    b.launch()
+    b.sync()
+    for q, (st, ro) in enumerate(refs):
+        res = b.get_result(q)
+        live = ro.j + (1 if ro.found else 0)
+        assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal
+        assert np.array_equal(res.parent[:live], ro.parent[:live]) and np.array_equal(res.vcost[:live], ro.vcost[:live])
+        assert np.array_equal(res.head[:live], ro.head[:live])
+    b.close()
+    plain = _ffi.Batch(gpu_ctx, 1, 100)
+    with pytest.raises(_ffi.RRTError):
+        plain.set_query(0, qu)
+    plain.close()
