@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="2-4: BASELINE.json configs[1..3]; 5: configs[4] (Dubins-RRT*, no reference parity)")
     ap.add_argument("--queries", type=int, default=None, help="queries per GPU (default: the config's)")
     ap.add_argument("--n", type=int, default=None)
-    ap.add_argument("--team", type=int, default=None, choices=[1, 2, 4, 8, 16, 32, 64],
+    ap.add_argument("--team", type=int, default=None, choices=[1, 2, 3, 4, 8, 16, 32, 64],
                     help="cap on the CUs per query (default: the largest team for which all teams are resident together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the informational batched leg (configs[3] share of one GPU)")

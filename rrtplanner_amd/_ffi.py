@@ -35,7 +35,7 @@ FLAG_DUBINS = 64
 
 def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=True, rewire=False, dubins=False):
     """flags word of rrt_plan / rrt_batch_create.  team: None = as many CUs per query as fit (up to 64), 1 = one CU,
-    2..64 = cap on the team size; pipe = False: teams of 8 and more do not pipeline super-blocks; team_fault = the
+    2..64 = cap on the team's workers; pipe = False: no pipelined teams (workers + one committing CU); team_fault = the
     fault-injection flag of the tests."""
     f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_TEAM_FAULT if team_fault else 0) | (0 if pipe else FLAG_NOPIPE)
     f |= FLAG_REWIRE if rewire else 0  # the opt-in true rewire (not the reference's behaviour)
@@ -43,8 +43,8 @@ def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=Tru
     if team == 1:
         f |= FLAG_NOTEAM
     elif team is not None:
-        if team not in (2, 4, 8, 16, 32, 64):
-            raise ValueError("team must be None, 1, 2, 4, 8, 16, 32 or 64")
+        if team not in (2, 3, 4, 8, 16, 32, 64):
+            raise ValueError("team must be None, 1, 2, 3, 4, 8, 16, 32 or 64")
         f |= int(team) << 8
     return f
 

@@ -422,7 +422,90 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         nlist = 0;
         float T = boundf;            // wave-uniform screen, tightens to the second cheapest so far
         uint32_t Thi = hi_of((double)boundf);
-        for (int c0 = part * CG; c0 < ncr; c0 += nparts * CG) {  // CG cells at a time: CG independent record loads in flight
+        // one 16-byte record per lane: hit test, parking, the screens and the exact price (rrt.py:176-181, :515-518)
+        auto eval_record = [&](const u32x4 rc, bool &dirty) {
+            const uint32_t d2 = dist2(rc.x, X);
+            const bool hit = d2 < r2 && (!check_j0 || rc.y < (uint32_t)j0);
+            hits += hit ? 1u : 0u;
+            // park everything whose vcost alone can be below the bound (the high word of a non-negative f64 is monotone)
+            const bool park = hit && rc.w <= boundhi;
+            const unsigned long long pm = __ballot(park);
+            if (pm == 0) return;
+            if (park) {
+                const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+                if (pos < clist_cap) clist[pos] = u32x4{rc.y, d2, rc.z, rc.w};
+            }
+            nlist += (uint32_t)__builtin_popcountll(pm);
+            // screens, cheapest first; none rejects an entry that belongs to the two cheapest
+            const bool pre = park && rc.w <= Thi;
+            if (__ballot(pre) == 0) return;
+            const double V = __longlong_as_double((long long)(((unsigned long long)rc.w << 32) | rc.z));
+            const bool maybe = pre && ((float)V + __builtin_amdgcn_sqrtf((float)d2) < T);
+            if (__ballot(maybe) == 0) return;
+            if (maybe) {
+                const double cn = V + sqrt_u24(d2);
+                if (cn < bound && !key_lt(cn, rc.y, lbc, lbi)) {  // rrt.py:518, strict
+                    tt.fold(cn, rc.y);
+                    const float cu = screen_of(cn);
+                    if (cu < m1) {
+                        m2 = m1;
+                        m1 = cu;
+                    } else if (cu < m2) {
+                        m2 = cu;
+                    }
+                }
+            }
+            dirty = true;
+        };
+        auto tighten = [&]() {  // the screen follows (an upper bound of) the wave's second cheapest so far
+            const float w1 = wave_min_f32_nonneg(m1);
+            const float w2 = wave_min_f32_nonneg(m1 == w1 ? m2 : m1);
+            T = w2 < boundf ? w2 : boundf;
+            Thi = hi_of((double)T);
+        };
+        if (ncr <= 64) {
+            // The records of all touched cells as ONE stream: lane l of a step takes record 64 * step + l of the concatenation of
+            // the cells' arrays, so a step is 64 live records whatever the fill of the single cells (a cell holds 10 - 30 nodes
+            // at these densities: cell by cell three lanes in four would idle).  Exclusive prefix sum of the fill counts over the
+            // lanes; a lane finds its cell by bisection over that prefix (ds_bpermute: the prefix stays in registers).
+            uint32_t incl = tcnt;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t pre = incl - tcnt;  // lanes past the last cell hold `total`: never <= a live record number
+            for (uint32_t base = (uint32_t)part * (64u * CG); base < total; base += (uint32_t)nparts * (64u * CG)) {  // CG steps in flight
+                u32x4 rc[CG];
+                bool live[CG];
+#pragma unroll
+                for (int g2 = 0; g2 < CG; ++g2) {
+                    const uint32_t idx = base + 64u * (uint32_t)g2 + (uint32_t)lane;
+                    uint32_t lo = 0;  // the largest cell c with pre[c] <= idx (an empty cell shares its prefix with its successor)
+#pragma unroll
+                    for (uint32_t bit = 32; bit != 0; bit >>= 1) {
+                        const uint32_t cand = lo + bit;
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cand << 2), (int)pre);
+                        lo = v <= idx ? cand : lo;
+                    }
+                    const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
+                    const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
+                    live[g2] = idx < total;
+                    rc[g2] = cellrec[live[g2] ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}; (record 0 exists: every cell array has a slot)
+                }
+                bool dirty = false;
+#pragma unroll
+                for (int g2 = 0; g2 < CG; ++g2) {
+                    if (base + 64u * (uint32_t)g2 >= total) continue;
+                    if (!live[g2]) rc[g2].x = 0x7fff7fffu;  // never within the radius
+                    eval_record(rc[g2], dirty);
+                }
+                if (dirty) tighten();
+            }
+        } else {
+        for (int c0 = part * CG; c0 < ncr; c0 += nparts * CG) {  // more than 64 cells (a radius far beyond the cell size): cell by cell, CG at a time
             uint32_t cnt[CG];
             const u32x4 *rec[CG];
             uint32_t maxc = 0;
@@ -434,7 +517,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     if (c0 + g2 < 64) {
                         cnt[g2] = (uint32_t)__builtin_amdgcn_readlane((int)tcnt, c0 + g2);
                         rec[g2] = cellrec + (uint32_t)__builtin_amdgcn_readlane((int)toff, c0 + g2);
-                    } else {  // more than 64 cells: a radius far beyond the cell size
+                    } else {
                         const int ci = c0 + g2, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
                         cnt[g2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cellcnt[cell]);
                         rec[g2] = cellrec + (size_t)cell * (size_t)ccap;
@@ -454,47 +537,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     if (!(s < cnt[g2])) rc[g2].x = 0x7fff7fffu;  // never within the radius
                 bool dirty = false;
 #pragma unroll
-                for (int g2 = 0; g2 < CG; ++g2) {
-                    const uint32_t d2 = dist2(rc[g2].x, X);
-                    const bool hit = d2 < r2 && (!check_j0 || rc[g2].y < (uint32_t)j0);
-                    hits += hit ? 1u : 0u;
-                    // park everything whose vcost alone can be below the bound (the high word of a non-negative f64 is monotone)
-                    const bool park = hit && rc[g2].w <= boundhi;
-                    const unsigned long long pm = __ballot(park);
-                    if (pm == 0) continue;
-                    if (park) {
-                        const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                        if (pos < clist_cap) clist[pos] = u32x4{rc[g2].y, d2, rc[g2].z, rc[g2].w};
-                    }
-                    nlist += (uint32_t)__builtin_popcountll(pm);
-                    // screens, cheapest first; none rejects an entry that belongs to the two cheapest
-                    const bool pre = park && rc[g2].w <= Thi;
-                    if (__ballot(pre) == 0) continue;
-                    const double V = __longlong_as_double((long long)(((unsigned long long)rc[g2].w << 32) | rc[g2].z));
-                    const bool maybe = pre && ((float)V + __builtin_amdgcn_sqrtf((float)d2) < T);
-                    if (__ballot(maybe) == 0) continue;
-                    if (maybe) {
-                        const double cn = V + sqrt_u24(d2);
-                        if (cn < bound && !key_lt(cn, rc[g2].y, lbc, lbi)) {  // rrt.py:518, strict
-                            tt.fold(cn, rc[g2].y);
-                            const float cu = screen_of(cn);
-                            if (cu < m1) {
-                                m2 = m1;
-                                m1 = cu;
-                            } else if (cu < m2) {
-                                m2 = cu;
-                            }
-                        }
-                    }
-                    dirty = true;
-                }
-                if (dirty) {  // tighten the screen to (an upper bound of) the wave's second cheapest so far
-                    const float w1 = wave_min_f32_nonneg(m1);
-                    const float w2 = wave_min_f32_nonneg(m1 == w1 ? m2 : m1);
-                    T = w2 < boundf ? w2 : boundf;
-                    Thi = hi_of((double)T);
-                }
+                for (int g2 = 0; g2 < CG; ++g2) eval_record(rc[g2], dirty);
+                if (dirty) tighten();
             }
+        }
         }
         nnear_part = wave_sum_u32(hits);
         tt.wave_reduce();
@@ -503,8 +549,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // Price this wave's parked entries once and compact the ones still open (cost < bound, key >= lower bound) to the front
     // of the list as {index, cells, cost}, then test them.  A sample behind a wall has dozens of cheaper-but-blocked
     // candidates; two per memory round trip made it the straggler of its block:
-    //   <= 16 open entries: rank them in (cost, index) order and test ranks 0-7, 8-15 (one wave per line of sight, 8 in flight)
-    //   more: every entry is tested, one line of sight per LANE.
+    // every open entry is tested, one line of sight per LANE.
     // (wc, wi) = the cheapest passing entry; every entry with a key up to it has been tested and holds its cell count.
     auto consume_list = [&](uint32_t X, double bound, double lbc, uint32_t lbi, uint32_t nlist, double &wc, uint32_t &wi, uint32_t &nval) {
         const float boundf = screen_of(bound);
@@ -530,72 +575,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             nval += (uint32_t)__builtin_popcountll(om);
         }
         if (nval == 0) return;  // every entry was tried
-        const bool batch = rad < 64;  // every near-set segment fits one 64-cell ballot
-        if (nval <= 16) {
-            u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
-            if ((uint32_t)lane < nval) e = clist[lane];
-            const unsigned long long kb = ((unsigned long long)e.w << 32) | e.z;  // non-negative doubles order like their bits
-            uint32_t rank = 0;
-            for (uint32_t jn = 0; jn < nval; ++jn) {
-                const unsigned long long kj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)e.w, (int)jn) << 32) |
-                                              (uint32_t)__builtin_amdgcn_readlane((int)e.z, (int)jn);
-                const uint32_t ij = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)jn);
-                rank += (kj < kb || (kj == kb && ij < e.x)) ? 1u : 0u;
-            }
-            const uint32_t step = batch ? (uint32_t)LOSB : 1u;
-            for (uint32_t r0 = 0; r0 < nval; r0 += step) {
-                unsigned long long m = __ballot((uint32_t)lane < nval && rank >= r0 && rank < r0 + step);
-                uint32_t ci[LOSB], cxy[LOSB], clo[LOSB], chi[LOSB];
-                int src[LOSB];
-                int nc = 0;
-#pragma unroll
-                for (int c = 0; c < LOSB; ++c) {
-                    ci[c] = NONE;
-                    cxy[c] = X;
-                    clo[c] = 0u;
-                    chi[c] = 0x7ff00000u;
-                    src[c] = 0;
-                    if (m != 0) {
-                        src[c] = (int)__builtin_ctzll(m);
-                        m &= m - 1;
-                        ci[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.x, src[c]);
-                        clo[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.z, src[c]);
-                        chi[c] = (uint32_t)__builtin_amdgcn_readlane((int)e.w, src[c]);
-                        nc = c + 1;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < LOSB; ++c)
-                    if (c < nc) cxy[c] = node_xy(ci[c]);
-                bool okc[LOSB];
-                int ccs[LOSB];
-                if (batch) {
-                    los_batch(og, H, cxy, nc, X, lane, okc, ccs);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < LOSB; ++c) {
-                        okc[c] = false;
-                        ccs[c] = 0;
-                    }
-                    okc[0] = los_wave(og, H, cxy[0], X, lane, ccs[0]);
-                }
-#pragma unroll
-                for (int c = 0; c < LOSB; ++c) {
-                    if (c < nc) {
-                        if (lane == src[c]) clist[lane].y = (uint32_t)ccs[c];  // cells read by this test, for count_tests
-                        const double cc = __longlong_as_double((long long)(((unsigned long long)chi[c] << 32) | clo[c]));
-                        if (okc[c] && key_lt(cc, ci[c], wc, wi)) {
-                            wc = cc;
-                            wi = ci[c];
-                        }
-                    }
-                }
-                if (wi != NONE) break;
-            }
-            return;
-        }
-        // many open entries: one line of sight PER LANE, 64 entries at a time, every entry tested (each lane walks its own
-        // segment, four cell loads in flight); the answer is the cheapest passing entry
+        // one line of sight PER LANE, 64 entries at a time, every open entry tested (each lane walks its own segment, 16 cell
+        // loads in flight); the answer is the cheapest passing entry.  (Ranking up to 16 open entries and testing them in
+        // (cost, index) order, one wave per line of sight and 8 in flight, was measured slower on every bench workload:
+        // profiles/r02_experiments.md.)
         for (uint32_t p0 = 0; p0 < nval; p0 += 64) {
             const uint32_t p = p0 + (uint32_t)lane;
             const bool have = p < nval;
@@ -606,17 +589,18 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const int L = ln.major;
             bool blocked = false;
             int cells = L + 1;
-            for (int k0 = 0; __any(!blocked && k0 <= L); k0 += 4) {
-                uint8_t v[4];
+            constexpr int WU = 16;
+            for (int k0 = 0; __any(!blocked && k0 <= L); k0 += WU) {
+                uint8_t v[WU];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {  // unconditional loads (clamped to the segment's last cell)
+                for (int u = 0; u < WU; ++u) {  // unconditional loads (clamped to the segment's last cell)
                     const int kk = (k0 + u) < L ? (k0 + u) : L;
                     int x, y;
                     rrt_line_cell(&ln, kk, &x, &y);
                     v[u] = og[(uint32_t)(x * H + y)];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < WU; ++u)
                     if (!blocked && k0 + u <= L && v[u] != 0) {
                         blocked = true;
                         cells = k0 + u + 1;
@@ -698,6 +682,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // steps [c0, c1) of the scan: 4096 nodes per step, from the LDS cache or (beyond it) from HBM, next step prefetched
     const uint32_t node0 = xs;  // node 0 = the start
     auto scan_steps = [&](int c0, int c1, int jlim, const uint32_t (&xs16)[BSM], uint32_t (&best)[BSM]) {
+#ifdef RRT_EXP_SCAN1
+        c1 = c1 > 1 ? 1 : c1;  // timing experiment only (wrong trees): what the run costs without the brute-force scan
+#endif
         const int nl = c1 < lds_chunks ? c1 : lds_chunks;
         if (c0 < nl) {
             u32x4 cur = nodes_lds4[c0 * TPB + t];
@@ -752,9 +739,16 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #pragma unroll
             for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + (size_t)(ep % NSLOT) * 8 + w, u.w[w], RRT_RLX_AGENT);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // wave 0 made every store of the commit
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the flag must not overtake the write-back
+#ifdef RRT_EXP_RELEASE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the old form: plain stores + an L2 write-back)
+#endif
+        // wave 0 made every store of the commit, all of them write-through (nodes, costs, parents, cell records, the bitmap's
+        // atomic, the logs' plain stores are host-read only): the flag only must not overtake them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
+        // this CU read lines of the arrays just extended through its L1 (the neighbours of the new entries); the stores above
+        // bypass it, so drop it like every other member does when it takes the commit
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     };
     while ((pipe_inf && g > 0) || i < n) {
         const int i0 = i, j0 = j;
@@ -882,6 +876,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #endif
         if constexpr (WPS == 1) {
         const int sidx = wg * BSM + wave;  // the sample this wave owns (waves BSM.. of a small-BSM team member idle here)
+#ifdef RRT_EXP_PRIO
+        // the arbiter issues the oldest wave first: without help the owners of the later samples of a SIMD fall behind and
+        // everybody waits for them at the barrier
+        if (wave >= 12) __builtin_amdgcn_s_setprio(3);
+        else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+        else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
         if (wave < BSM && sidx < nb) {
             const int k = wave;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, sidx);  // every wave holds the same xv
@@ -903,6 +904,19 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const u64 nnmask = __ballot(lane < sidx && dk < d2s);
             const u64 rmask = __ballot(lane < sidx && star && dk < r2);
             const u64 dupmask = __ballot(lane < sidx && xo == Xk);
+            u64 pnn[2] = {0, 0}, pr[2] = {0, 0}, pdup[2] = {0, 0};
+            if (PIPE) {  // ... and every sample of the blocks in flight, which are being committed meanwhile
+#pragma unroll
+                for (int p2 = 0; p2 < NP; ++p2) {
+                    if (p2 < nprev) {
+                        const uint32_t xop = xqp_lds[p2][lane];
+                        const uint32_t dp = dist2(xop, Xk);
+                        pnn[p2] = __ballot(dp < d2s);
+                        pr[p2] = __ballot(star && dp < r2);
+                        pdup[p2] = __ballot(xop == Xk);
+                    }
+                }
+            }
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
             const double cnear_s = Vs + sqrt_u32(d2s);
@@ -931,10 +945,18 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 r.nnear = nnear;
                 r.pad = 0;
                 r.pc = pc;
-                r.pnn[0] = r.pnn[1] = r.pr[0] = r.pr[1] = r.pdup[0] = r.pdup[1] = 0;
+                r.pnn[0] = pnn[0];
+                r.pnn[1] = pnn[1];
+                r.pr[0] = pr[0];
+                r.pr[1] = pr[1];
+                r.pdup[0] = pdup[0];
+                r.pdup[1] = pdup[1];
                 brec[0][sidx] = r;
             }
         }
+#ifdef RRT_EXP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         } else {
             // ---- a group of WPS waves per sample: every wave streams its share of the cells; the group's first wave (leader)
             //      combines, tests lines of sight and writes the record; blocked-candidate lists are tested by all WPS waves ----
@@ -1779,17 +1801,31 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         statred[lane * 5 + 3] += f.pstat & 0xfffffu;
                     }
                     const uint32_t cellbit = (uint32_t)ux(xv) * (uint32_t)H + (uint32_t)uy(xv);
-                    at32(nodes_g, (uint32_t)jmine) = xv;
                     if (jmine < lds_nodes) nodes_lds[jmine] = xv;
-                    at32(vcost, (uint32_t)jmine) = f.cbest;
-                    at32(parent, (uint32_t)jmine) = (int32_t)f.vbest;
+                    const unsigned long long cb = (unsigned long long)__double_as_longlong(f.cbest);
+                    if (G > 1) {
+                        // a team: exactly the bytes the other members will read go out write-through (agent-scope stores), so
+                        // that publishing the block needs no L2 write-back, only the wait for these stores
+                        __hip_atomic_store((gu32 *)&at32(nodes_g, (uint32_t)jmine), xv, RRT_RLX_AGENT);
+                        __hip_atomic_store((gu64 *)&at32(vcost, (uint32_t)jmine), (u64)cb, RRT_RLX_AGENT);
+                        __hip_atomic_store((gu32 *)&at32(parent, (uint32_t)jmine), f.vbest, RRT_RLX_AGENT);
+                    } else {
+                        at32(nodes_g, (uint32_t)jmine) = xv;
+                        at32(vcost, (uint32_t)jmine) = f.cbest;
+                        at32(parent, (uint32_t)jmine) = (int32_t)f.vbest;
+                    }
                     atomicOr(&at32(bitmap, cellbit >> 5), 1u << (cellbit & 31));  // rrt.py:426
                     if (star) {
                         const int c = cell_of(xv);
                         const uint32_t slot = __hip_atomic_fetch_add(&cellcnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const unsigned long long cb = (unsigned long long)__double_as_longlong(f.cbest);
                         u32x4 rc = {xv, (uint32_t)jmine, (uint32_t)cb, (uint32_t)(cb >> 32)};
-                        at32(cellrec, (uint32_t)c * (uint32_t)ccap + slot) = rc;
+                        if (G > 1) {  // (a reader takes a record only after the go flag: two 8-byte halves cannot be seen torn)
+                            gu64 *dst = (gu64 *)&at32(cellrec, (uint32_t)c * (uint32_t)ccap + slot);
+                            __hip_atomic_store(dst, ((u64)jmine << 32) | xv, RRT_RLX_AGENT);
+                            __hip_atomic_store(dst + 1, (u64)cb, RRT_RLX_AGENT);
+                        } else {
+                            at32(cellrec, (uint32_t)c * (uint32_t)ccap + slot) = rc;
+                        }
                     }
                 }
                 j = j0 + __builtin_popcountll(acc_exact);

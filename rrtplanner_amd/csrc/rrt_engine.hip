@@ -51,7 +51,8 @@ struct rrt_batch {
     bool use_block = false;     // block-parallel kernel (rrt_block.h) instead of the one-sample-per-iteration kernel
     int32_t blk_lds_chunks = 1; // node chunks cached in LDS by the block kernel
     size_t blk_lds_bytes = 0;
-    int32_t team = 1;           // workgroups (CUs) per query of the block kernel (rrt_block.h, teams)
+    int32_t team = 1;           // workgroups (CUs) per query of the block kernel that scan and resolve (rrt_block.h, teams)
+    bool pipe_team = false;     // the team is pipelined: one more workgroup per query, which only commits
     bool pipe = false;          // the last launch ran the pipelined team kernel
     int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
     int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
@@ -392,25 +393,28 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
 #endif
         b->team = 1;
         b->team_qpad = (Q + 7) & ~7;
-        int pipe_team = 0, pipe_stride = 0;  // the largest team of 8+ that also has room for its committer (pipelined)
-        for (int g : {2, 4, 8, 16, 32, 64}) {
+        auto stride_of = [&](int g) {
             const int step = g <= 16 ? 8 : (g == 32 ? 4 : 2);
             int stride = ((Q + step - 1) / step) * step;
             if (g == 32 && stride % 8 == 0) stride += 4;
             if (g == 64 && stride % 4 == 0) stride += 2;
-            if (g <= want && stride * g <= ctx->num_cu) {
+            return stride;
+        };
+        for (int g : {2, 4, 8, 16, 32, 64})
+            if (g <= want && stride_of(g) * g <= ctx->num_cu) {
                 b->team = g;
-                b->team_qpad = stride;
+                b->team_qpad = stride_of(g);
             }
-            if (g >= 8 && g <= want && !(flags & RRT_FLAG_NOPIPE) && stride * (g + 1) <= ctx->num_cu) {
-                pipe_team = g;
-                pipe_stride = stride;
-            }
-        }
-        // a pipelined team beats an unpipelined one of twice its size (config 2: 8+1 CUs 24.7 ms vs 16 CUs 27.3 ms, ...)
-        if (pipe_team != 0 && b->team <= 2 * pipe_team) {
-            b->team = pipe_team;
-            b->team_qpad = pipe_stride;
+        // pipelined teams: g workers and a committer (g + 1 CUs).  A pipelined team beats an unpipelined one of twice its size
+        // (config 2: 8+1 CUs 24.7 ms vs 16 CUs 27.3 ms; config 4's share: 3+1 CUs vs 4 CUs, profiles/r02_experiments.md)
+        int pipe_g = 0;
+        if (!(flags & RRT_FLAG_NOPIPE))
+            for (int g : {2, 3, 4, 8, 16, 32, 64})
+                if (g <= want && stride_of(g) * (g + 1) <= ctx->num_cu) pipe_g = g;
+        if (pipe_g != 0 && b->team <= 2 * pipe_g) {
+            b->team = pipe_g;
+            b->team_qpad = stride_of(pipe_g);
+            b->pipe_team = true;
         }
     }
     b->spill_stride = chunks * CHUNK * (b->team + 1);  // per member (and a pipelined team's committer): 256 parked entries per wave and node chunk; also go2goal's cost array
@@ -639,7 +643,10 @@ static block_kernel_fn block_kernel_fn_inf(int team, bool pipe) {
             case 64: return rrt_expand_block_kernel<64, 1, true, INF>;
             case 32: return rrt_expand_block_kernel<32, 2, true, INF>;
             case 16: return rrt_expand_block_kernel<16, 4, true, INF>;
-            default: return rrt_expand_block_kernel<8, 8, true, INF>;
+            case 8: return rrt_expand_block_kernel<8, 8, true, INF>;
+            case 4: return rrt_expand_block_kernel<4, 16, true, INF>;
+            case 3: return rrt_expand_block_kernel<3, 16, true, INF>;
+            default: return rrt_expand_block_kernel<2, 16, true, INF>;
         }
     }
     switch (team) {
@@ -667,7 +674,8 @@ static size_t block_kernel_static_lds(int team) {
     for (int g : {team, 1})
         for (bool pipe : {false, true})
             for (bool inf : {false, true}) {
-                if (pipe && g < 8) continue;
+                if (pipe && g < 2) continue;
+                if (!pipe && g == 3) continue;  // (three workers exist only as a pipelined team)
                 if (hipFuncGetAttributes(&a, block_kernel_of(g, pipe, inf)) != hipSuccess) return 16384;
                 worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
             }
@@ -694,7 +702,7 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         const int team = b->one_cu_once ? 1 : b->team;
         b->one_cu_once = false;
         // a two-deep pipeline of super-blocks (one more workgroup per team, which only commits) for teams of 8 and more
-        bool pipe = team >= 8 && !(b->flags & RRT_FLAG_NOPIPE) && b->team_qpad * (team + 1) <= ctx->num_cu;
+        bool pipe = team > 1 && b->pipe_team;
 #ifdef RRT_STAMPS
         if (const char *e = getenv("RRT_PIPE")) pipe = pipe && atoi(e) != 0;  // diagnostic build only
 #endif

@@ -160,11 +160,12 @@ def test_replan_chain_rng_continues_and_set_og(tag):
 
 
 # ------------------------------------------------------------------------------- device vs oracle, larger
-# teams of up to 64 CUs per query (default; 8 and more: pipelined super-blocks for RRTStandard / RRTStar), the same without the
-# pipeline, capped teams (2 and 4: 16 samples per member; 16: 4 samples per member, 4 waves per sample), one CU, one sample per
-# iteration, and a team that loses a member (must finish on one CU per query)
-KERNELS = ["team", "teamnp", "team2", "team4", "team16", "block", "serial", "teamfault"]
-_KERNEL_ARGS = {"team": {}, "teamnp": {"pipe": False}, "team2": {"team": 2}, "team4": {"team": 4}, "team16": {"team": 16},
+# teams of up to 64 workers per query (default: pipelined, one more CU that only commits), the same without the pipeline, capped
+# teams (2, 3 and 4 workers: 16 samples per member, pipelined and -- 4 -- not; 16: 4 samples per member, 4 waves per sample), one CU,
+# one sample per iteration, and a team that loses a member (must finish on one CU per query)
+KERNELS = ["team", "teamnp", "team2", "team3", "team4", "team4np", "team16", "block", "serial", "teamfault"]
+_KERNEL_ARGS = {"team": {}, "teamnp": {"pipe": False}, "team2": {"team": 2}, "team3": {"team": 3}, "team4": {"team": 4},
+                "team4np": {"team": 4, "pipe": False}, "team16": {"team": 16},
                 "block": {"team": 1}, "serial": {"serial": True}, "teamfault": {"team": 8, "team_fault": True}}
 KERNELS_NOFAULT = [k for k in KERNELS if k != "teamfault"]
 
@@ -355,7 +356,8 @@ def _bench_config4_queries(og, free, Q, n, first=0, stride=1):
 
 def test_config4_share_of_one_gpu_equals_the_oracle(gpu_ctx):
     """BASELINE configs[3]'s per-GPU share exactly as bench.py's `batched` leg runs it: 64 independent RRT* queries, n = 20000,
-    r_rewire = 64, the 1024x1024 bench grid, default teams (4 CUs per query, all 256 CUs busy, 64 teams contending for L2).
+    r_rewire = 64, the 1024x1024 bench grid, default teams (3 workers + 1 committer per query, all 256 CUs busy, 64 teams
+    contending for L2).
     Every query's nodes, parents and costs must equal the oracle's, no hand-off may time out, and a second launch after
     rearm must reproduce them."""
     og = perlin_occupancygrid(1024, 1024, seed=1)
@@ -375,7 +377,7 @@ def test_config4_share_of_one_gpu_equals_the_oracle(gpu_ctx):
     for rep in range(2):
         b.launch()
         b.sync()
-        assert b.team() == (4, 0)
+        assert b.team() == (3, 0) and b.pipelined()  # 64 x (3 workers + 1 committer) = all 256 CUs
         for q in range(Q):
             res = b.get_result(q)
             st, ro = refs[q]
@@ -570,7 +572,8 @@ def test_every_team_size_gives_the_same_trees_every_time(gpu_ctx):
         samples = hostprep.draw_free_samples(np.random.default_rng(q), free, n)
         qs.append(_ffi.make_query(1, n, xs, xg, samples, r2_rewire=hostprep.radius_threshold(64)))
     ref = None
-    for team, pipe in ((None, True), (None, False), (32, True), (16, True), (16, False), (8, True), (4, True), (2, True), (1, True)):
+    for team, pipe in ((None, True), (None, False), (32, True), (16, True), (16, False), (8, True), (4, True), (4, False), (3, True), (2, True),
+                       (2, False), (1, True)):
         b = _ffi.Batch(gpu_ctx, Q, n, team=team, pipe=pipe)
         for q, (qu, keep) in enumerate(qs):
             b.set_query(q, qu)

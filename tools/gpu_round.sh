@@ -19,6 +19,22 @@ bench)
     python3 $R/bench.py --queries 256 --no-cpu-baseline --no-batched > $O/bench_config2_q256.json 2>/dev/null
     for t in 1 2 4 8 16 32; do python3 $R/bench.py --team $t --no-cpu-baseline --no-batched > $O/bench_config2_team$t.json 2>/dev/null; done
     for t in 1 2 4 8; do python3 $R/bench.py --config 4 --team $t --no-cpu-baseline > $O/bench_config4_team$t.json 2>/dev/null; done ;;
+quick)
+    python3 $R/bench.py --no-cpu-baseline > $O/q_default.json 2>$O/q_default.err; echo "default rc=$?"
+    python3 $R/bench.py --config 4 --team 1 --no-cpu-baseline > $O/q_c4_team1.json 2>/dev/null
+    python3 $R/bench.py --config 3 --no-cpu-baseline --no-batched > $O/q_c3.json 2>/dev/null
+    python3 $R/bench.py --team 1 --no-cpu-baseline --no-batched > $O/q_c2_team1.json 2>/dev/null
+    python3 - <<PY
+import json
+for f in ("q_default","q_c4_team1","q_c3","q_c2_team1"):
+    try:
+        d=json.load(open("$O/"+f+".json"))
+        b=d.get("batched")
+        print(f, "kernel_ms=%.3f value=%.4g"%(d["roofline"]["kernel_ms"], d["value"]), ("batched kernel_ms=%.3f value=%.4g"%(b["roofline"]["kernel_ms"], b["value"])) if b else "")
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+    ;;
 prof)
     for c in 2 3 4; do
         rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline --no-batched > $O/prof_c$c.json 2> $O/prof_c$c.err
