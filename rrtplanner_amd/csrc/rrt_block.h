@@ -185,10 +185,13 @@ struct GSlot {
     double c1, c2;        // after stream_cells: the share's two cheapest; after consume_list: c1 = its cheapest passing entry
     uint32_t i1, i2;
     uint32_t hits, nlist; // after stream_cells: |within| of the share, parked entries; after consume_list: nlist = open entries
+    uint32_t nn_d2, nn_idx;  // after stream_cells: the nearest of the share's hits (NONE: no hit)
+    uint32_t pad[2];
 };
 struct GCtl {
     double lbc;
     uint32_t lbi, consume;  // consume: the two cheapest are blocked, every wave tests its own parked entries above (lbc, lbi)
+    double bound;           // the cost through the nearest node (the group's waves learn it from the leader)
 };
 
 union BlkWords {
@@ -401,8 +404,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     auto hi_of = [](double c) -> uint32_t { return (uint32_t)((unsigned long long)__double_as_longlong(c) >> 32); };
     const float FINF = __uint_as_float(0x7f800000u);
 
+    // nn_d2 / nn_idx: the nearest of the hits (smallest d2, lowest index among equals; NONE / NONE without a hit).  A hit lies
+    // within r_rewire, and every node outside the streamed cells is farther than that: if there is a hit, this IS the nearest
+    // node of the whole snapshot (near()[0], rrt.py:150-155) -- the brute-force scan is only needed when the ball is empty.
     auto stream_cells = [&](uint32_t X, int j0, bool check_j0, double bound, double lbc, uint32_t lbi, int part, int nparts, Top2 &tt,
-                            uint32_t &nnear_part, uint32_t &nlist) {
+                            uint32_t &nnear_part, uint32_t &nlist, uint32_t &nn_d2, uint32_t &nn_idx) {
         const int x = ux(X), y = uy(X);
         const int cx0 = (x - rad < 0 ? 0 : x - rad) >> cshift, cx1 = (x + rad > W - 1 ? W - 1 : x + rad) >> cshift;
         const int cy0 = (y - rad < 0 ? 0 : y - rad) >> cshift, cy1 = (y + rad > H - 1 ? H - 1 : y + rad) >> cshift;
@@ -419,6 +425,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         tt.init();
         float m1 = FINF, m2 = FINF;  // this lane's two cheapest verified entries, rounded up to f32
         uint32_t hits = 0;
+        uint32_t ld2 = NONE, lidx = NONE;  // this lane's nearest hit
         nlist = 0;
         float T = boundf;            // wave-uniform screen, tightens to the second cheapest so far
         uint32_t Thi = hi_of((double)boundf);
@@ -427,6 +434,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const uint32_t d2 = dist2(rc.x, X);
             const bool hit = d2 < r2 && (!check_j0 || rc.y < (uint32_t)j0);
             hits += hit ? 1u : 0u;
+            if (hit && (d2 < ld2 || (d2 == ld2 && rc.y < lidx))) {
+                ld2 = d2;
+                lidx = rc.y;
+            }
             // park everything whose vcost alone can be below the bound (the high word of a non-negative f64 is monotone)
             const bool park = hit && rc.w <= boundhi;
             const unsigned long long pm = __ballot(park);
@@ -544,6 +555,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         }
         nnear_part = wave_sum_u32(hits);
         tt.wave_reduce();
+        nn_d2 = ld2;
+        nn_idx = lidx;
+        wave_min_key_idx(nn_d2, nn_idx);
     };
 
     // Price this wave's parked entries once and compact the ones still open (cost < bound, key >= lower bound) to the front
@@ -638,17 +652,16 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 
     // One whole wave on its own.  Returns (pc, pi) or (inf, NONE); nnear = |within| over nodes [0, j0).
     auto snapshot_parent = [&](uint32_t X, int j0, bool check_j0, double bound, double &pc, uint32_t &pi, uint32_t &nnear,
-                               uint32_t &ntests, uint32_t &tcells) {
+                               uint32_t &ntests, uint32_t &tcells, double lbc = -1.0, uint32_t lbi = 0) {
         pc = f64_inf();
         pi = NONE;
         nnear = 0;
         if (r2 == 0) return;
-        double lbc = -1.0;
-        uint32_t lbi = 0;
         for (;;) {
             Top2 tt;
             uint32_t nlist = 0;
-            stream_cells(X, j0, check_j0, bound, lbc, lbi, 0, 1, tt, nnear, nlist);
+            uint32_t nd2, nidx;
+            stream_cells(X, j0, check_j0, bound, lbc, lbi, 0, 1, tt, nnear, nlist, nd2, nidx);
             if (tt.i1 == NONE) return;
             // the two cheapest, both lines of sight in flight together (rrt.py:519); the second counts only if needed
             bool ok1, ok2;
@@ -677,6 +690,71 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             count_tests(clist, nval, pc, pi, ntests, tcells);
             return;
         }
+    };
+
+    // ---- nearest node from the record stream (owners of RRT* samples) ---------------------------------------------------
+    // The owner streams the cells of the ball ONCE, without a bound (the bound is the cost through the nearest node, which the
+    // same stream finds): top two of all hits, all hits parked, and the nearest hit = near()[0] of the whole snapshot whenever
+    // the ball holds a node.  The brute-force scan of the node array (phase A) then never runs; a sample whose ball is empty --
+    // the first samples of a run, pockets the tree has not reached -- gets its nearest from one wave's own pass over the nodes.
+    // Used when the radius spans at least a cell; smaller radii keep phase A (the ball is empty too often).
+    const bool grid_nn = star && rad >= 16;
+    // what snapshot_parent does behind its stream, for a stream that ran without the bound
+    auto finish_parent = [&](uint32_t X, int j0, double bound, Top2 tt, uint32_t nlist, double &pc, uint32_t &pi, uint32_t &ntests, uint32_t &tcells) {
+        pc = f64_inf();
+        pi = NONE;
+        if (tt.i1 == NONE || !(tt.c1 < bound)) return;  // rrt.py:518, strict
+        if (tt.i2 != NONE && !(tt.c2 < bound)) tt.i2 = NONE;
+        bool ok1, ok2;
+        int cc1, cc2;
+        los_wave2(og, H, node_xy(tt.i1), tt.i2 != NONE ? node_xy(tt.i2) : X, tt.i2 != NONE, X, lane, ok1, cc1, ok2, cc2);
+        ntests += 1;
+        tcells += (uint32_t)cc1;
+        if (ok1) {
+            pc = tt.c1;
+            pi = tt.i1;
+            return;
+        }
+        if (tt.i2 == NONE) return;
+        ntests += 1;
+        tcells += (uint32_t)cc2;
+        if (ok2) {
+            pc = tt.c2;
+            pi = tt.i2;
+            return;
+        }
+        if (nlist > clist_cap) {  // the list overflowed: stream again, bounded, above the two that are blocked
+            uint32_t nn2 = 0;
+            snapshot_parent(X, j0, false, bound, pc, pi, nn2, ntests, tcells, tt.c2, tt.i2 + 1);
+            return;
+        }
+        uint32_t nval = 0;
+        consume_list(X, bound, tt.c2, tt.i2 + 1, nlist, pc, pi, nval);
+        count_tests(clist, nval, pc, pi, ntests, tcells);
+    };
+    // near()[0] (rrt.py:150-155) of one sample over the snapshot [0, j0) by ONE wave: 256 nodes per step, 4 per lane
+    auto wave_scan_nearest = [&](uint32_t X, int j0, uint32_t &d2s, uint32_t &vs) {
+        uint32_t bd = NONE, bi = NONE;
+        for (int base = 0; base < j0; base += 256) {
+            const int idx0 = base + 4 * lane;
+            if (idx0 < j0) {
+                u32x4 v;
+                if (idx0 < lds_nodes) v = nodes_lds4[idx0 >> 2];
+                else v = nodes_g4[idx0 >> 2];
+                const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t d = dist2(pv[e], X);
+                    if (idx0 + e < j0 && d < bd) {  // (a lane meets its nodes in index order: strict < keeps the lowest index)
+                        bd = d;
+                        bi = (uint32_t)(idx0 + e);
+                    }
+                }
+            }
+        }
+        wave_min_key_idx(bd, bi);
+        d2s = bd;
+        vs = bi;
     };
 
     // steps [c0, c1) of the scan: 4096 nodes per step, from the LDS cache or (beyond it) from HBM, next step prefetched
@@ -827,9 +905,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             xs16[k] = X << 4;
         }
 
-        // ---------------- A: scan the snapshot for all samples of the block ----------------
+        // ---------------- A: scan the snapshot for all samples of the block (not when the owners take the nearest node from
+        //                  the record stream) ----------------
         const int nsteps = (j0 + CHUNK - 1) / CHUNK;
-        {
+        if (!grid_nn) {
             uint32_t best[BSM];
             int c_first = 0;
             if (G > 1 && pre_i == i0) {  // steps [0, pre_j) were scanned while member 0 committed; unfilled slots held node 0
@@ -887,12 +966,26 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const int k = wave;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, sidx);  // every wave holds the same xv
             uint32_t d2s = NONE, vs = NONE;
-            if (lane < NWAVE) {
-                const u32x2 v = ((RRT_LDS u32x2 *)nnx)[k * NWAVE + lane];
-                d2s = v.x;
-                vs = v.y;
+            Top2 tt0;
+            tt0.init();
+            uint32_t nlist0 = 0, nnear0 = 0;
+            if (grid_nn) {  // the record stream first: it names the nearest node unless the ball is empty
+                uint32_t nd2, nidx;
+                stream_cells(Xk, j0, false, f64_inf(), -1.0, 0u, 0, 1, tt0, nnear0, nlist0, nd2, nidx);
+                if (nnear0 != 0) {
+                    d2s = nd2;
+                    vs = nidx;
+                } else {
+                    wave_scan_nearest(Xk, j0, d2s, vs);
+                }
+            } else {
+                if (lane < NWAVE) {
+                    const u32x2 v = ((RRT_LDS u32x2 *)nnx)[k * NWAVE + lane];
+                    d2s = v.x;
+                    vs = v.y;
+                }
+                wave_min_key_idx(d2s, vs);
             }
-            wave_min_key_idx(d2s, vs);
             const double Vs = at32(vcost, vs);
             const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
             const uint32_t bm_word = at32(bitmap, cell >> 5);
@@ -923,7 +1016,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #ifdef RRT_STAMPS
             const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (star) snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);  // no block node is in the cells yet
+            if (grid_nn) {
+                nnear = nnear0;
+                if (nnear0 != 0) finish_parent(Xk, j0, cnear_s, tt0, nlist0, pc, pi, ntests, tcells);
+            } else if (star) {
+                snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);  // no block node is in the cells yet
+            }
 #ifdef RRT_STAMPS
             wcyc_los += __builtin_amdgcn_s_memtime() - tl0;
 #endif
@@ -965,14 +1063,17 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const bool act = sidx < nb, lead = part == 0;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, act ? sidx : 0);
             uint32_t d2s = NONE, vs = NONE;
-            if (lane < NWAVE) {
-                const u32x2 v = ((RRT_LDS u32x2 *)nnx)[sl * NWAVE + lane];
-                d2s = v.x;
-                vs = v.y;
+            double Vs = 0.0, cnear_s = f64_inf();  // (grid_nn: known to the leader after the stream, to the others from gctl)
+            if (!grid_nn) {
+                if (lane < NWAVE) {
+                    const u32x2 v = ((RRT_LDS u32x2 *)nnx)[sl * NWAVE + lane];
+                    d2s = v.x;
+                    vs = v.y;
+                }
+                wave_min_key_idx(d2s, vs);
+                Vs = act ? at32(vcost, vs) : 0.0;
+                cnear_s = Vs + sqrt_u32(d2s);
             }
-            wave_min_key_idx(d2s, vs);
-            const double Vs = act ? at32(vcost, vs) : 0.0;
-            const double cnear_s = Vs + sqrt_u32(d2s);
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
             bool free_s = false;
@@ -985,7 +1086,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             LosPending lp;
             lp.major = 0;
             lp.v = 0;
-            if (lead && act) {  // started here, finished behind the near-set stream
+            if (lead && act && !grid_nn) {  // started here, finished behind the near-set stream
                 bm_word = at32(bitmap, cell >> 5);
                 vsxy = node_xy(vs);
                 lp = los_issue(og, H, vsxy, Xk, lane);
@@ -993,8 +1094,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (star) {
                 Top2 tt;
                 tt.init();
-                uint32_t hp = 0;
-                if (act) stream_cells(Xk, j0, false, cnear_s, -1.0, 0u, part, WPS, tt, hp, own_nlist);
+                uint32_t hp = 0, nd2 = NONE, nidx = NONE;
+                if (act) stream_cells(Xk, j0, false, cnear_s, -1.0, 0u, part, WPS, tt, hp, own_nlist, nd2, nidx);  // (grid_nn: no bound yet)
                 if (lane == 0) {
                     GSlot sl_;
                     sl_.c1 = tt.c1;
@@ -1003,6 +1104,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     sl_.i2 = tt.i2;
                     sl_.hits = hp;
                     sl_.nlist = own_nlist;
+                    sl_.nn_d2 = nd2;
+                    sl_.nn_idx = nidx;
+                    sl_.pad[0] = sl_.pad[1] = 0;
                     gslot[wave] = sl_;
                 }
                 __syncthreads();
@@ -1011,6 +1115,26 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             double lbc = -1.0;
             uint32_t lbi = 0;
             if (lead && act) {
+                if (grid_nn) {  // the nearest of the shares' hits is the nearest node; an empty ball: this wave scans the nodes
+                    uint32_t gd = NONE, gi = NONE, gh = 0;
+                    if (lane < WPS) {
+                        gd = gslot[sl * WPS + lane].nn_d2;
+                        gi = gslot[sl * WPS + lane].nn_idx;
+                        gh = gslot[sl * WPS + lane].hits;
+                    }
+                    wave_min_key_idx(gd, gi);
+                    if (wave_sum_u32(gh) != 0) {
+                        d2s = gd;
+                        vs = gi;
+                    } else {
+                        wave_scan_nearest(Xk, j0, d2s, vs);
+                    }
+                    Vs = at32(vcost, vs);
+                    cnear_s = Vs + sqrt_u32(d2s);
+                    bm_word = at32(bitmap, cell >> 5);
+                    vsxy = node_xy(vs);
+                    lp = los_issue(og, H, vsxy, Xk, lane);
+                }
                 free_s = los_finish(lp, og, H, vsxy, Xk, lane, cells);
                 // earlier samples of this block that could interact once inserted
                 const uint32_t xo = (lane < sidx) ? xq_lds[lane] : Xk;
@@ -1037,8 +1161,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #pragma unroll
                     for (int pp = 0; pp < WPS; ++pp) {
                         const GSlot o = gslot[sl * WPS + pp];
-                        if (o.i1 != NONE) tt.fold(o.c1, o.i1);
-                        if (o.i2 != NONE) tt.fold(o.c2, o.i2);
+                        if (o.i1 != NONE && o.c1 < cnear_s) tt.fold(o.c1, o.i1);  // (grid_nn: the shares streamed without the bound)
+                        if (o.i2 != NONE && o.c2 < cnear_s) tt.fold(o.c2, o.i2);
                         nnear += o.hits;
                         overflow = overflow || o.nlist > clist_cap;
                     }
@@ -1076,6 +1200,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     c.lbc = lbc;
                     c.lbi = lbi;
                     c.consume = (act && consume) ? 1u : 0u;
+                    c.bound = cnear_s;
                     gctl[sl] = c;
                 }
                 __syncthreads();
@@ -1083,7 +1208,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (c.consume != 0u) {  // every wave of the group: its own parked entries above the lower bound
                     double wc;
                     uint32_t wi, nval;
-                    consume_list(Xk, cnear_s, c.lbc, c.lbi, own_nlist, wc, wi, nval);
+                    consume_list(Xk, c.bound, c.lbc, c.lbi, own_nlist, wc, wi, nval);
                     if (lane == 0) {
                         GSlot sl_;
                         sl_.c1 = wc;
@@ -1180,7 +1305,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             // block's samples (known: only an Informed block can be cut short); after the take only the steps that hold new
             // nodes are left.
             pre_i = -1;
-            if (!informed && more) {
+            if (!informed && more && !grid_nn) {
                 pre_i = i0 + nb;
                 pre_j = j0;
                 const int nbn = (n - pre_i) < SB ? (n - pre_i) : SB;
@@ -1272,7 +1397,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
             }
             pre_i = -1;
-            if (!informed && i0 + nb < n) {  // the next block's samples are known (only an Informed block can be cut short)
+            if (!informed && i0 + nb < n && !grid_nn) {  // the next block's samples are known (only an Informed block can be cut short)
                 pre_i = i0 + nb;
                 pre_j = j0;
                 const int nbn = (n - pre_i) < SB ? (n - pre_i) : SB;
