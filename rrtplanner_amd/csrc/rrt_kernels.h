@@ -547,9 +547,17 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         double my_vc_nn = 0.0;
         if (ki != NONE) {
             my_vc_nn = node_cost(ki);
-            if (DUB) my_vc_nn += edge_len(ki, kd);  // the cost through the local nearest: the word's length is not a function of d2
             int cells = 0;
-            const bool ok = edge_free(ki, cells);
+            bool ok;
+            if (DUB) {  // one word evaluation serves the cost through the local nearest (not a function of d2) and its sweep
+                const uint32_t a = node_xy(ki);
+                const int ha = node_h(ki);
+                const dub_path_t pth = dub_between_dev(a, ha, xq, hq, dc);
+                my_vc_nn += pth.len;
+                ok = dub_sweep_wave(og, dc, a, ha, xq, pth, lane, cells);
+            } else {
+                ok = edge_free(ki, cells);
+            }
             my_nn_los = (ok ? 0x80000000u : 0u) | (uint32_t)cells;
         }
         // (b) price this wave's near-set entries, keep them in registers; best and second best
