@@ -44,47 +44,69 @@ def _launcher_key() -> str:
     return f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}"
 
 
+def _id_paths(path):
+    """(launcher-keyed file, port-keyed fallback file).  All ranks of a torch.distributed.run launch are children of one agent
+    process, so the first name is shared and unique; a launcher that starts the ranks from different parents still agrees on
+    the rendezvous port, which names the fallback."""
+    if path is not None:
+        return path, None
+    base = os.environ.get("RRT_COMM_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    return (os.path.join(base, f"rrt_comm_{_launcher_key()}.id"),
+            os.path.join(base, f"rrt_comm_port_{os.environ.get('MASTER_ADDR', 'local')}_{os.environ.get('MASTER_PORT', '0')}.id"))
+
+
+_T_START = time.time()
+
+
 def exchange_unique_id(rank: int, world_size: int, make_id, path: str = None, timeout: float = 120.0) -> bytes:
     """Rank 0 calls `make_id()` (-> 128 bytes, ``_ffi.comm_unique_id``) and publishes the result; the other ranks of the
     node wait for it.  Single node, so a file on local tmpfs is the side channel: written under a temporary name and
-    renamed, so a reader sees all of it or nothing.  Rank 0 removes the file in `release_unique_id` once the
-    communicator exists (ncclCommInitRank returns only after every rank has joined, i.e. has read the file)."""
+    renamed, so a reader sees all of it or nothing.  Rank 0 removes the files in `release_unique_id` once the
+    communicator exists (ncclCommInitRank returns only after every rank has joined, i.e. has read the id).  The port-keyed
+    fallback is only accepted when it is fresh (written after this process started, give or take a few seconds): a file a
+    crashed earlier run left behind is ignored."""
     if world_size < 1 or not (0 <= rank < world_size):
         raise ValueError(f"bad rank {rank} of {world_size}")
-    if path is None:
-        base = os.environ.get("RRT_COMM_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
-        path = os.path.join(base, f"rrt_comm_{_launcher_key()}.id")
+    main, fallback = _id_paths(path)
     if rank == 0:
         uid = bytes(make_id())
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
+        for target in (main, fallback):
+            if target is None:
+                continue
+            tmp = f"{target}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, target)
         return uid
-    deadline = time.monotonic() + timeout
+    t0 = time.monotonic()
+    deadline = t0 + timeout
     while True:
-        try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) > 0:
-                return uid
-        except OSError:
-            pass
+        for target, fresh_only in ((main, False), (fallback, True)):
+            if target is None or (fresh_only and time.monotonic() - t0 < 3.0):  # the fallback only after the shared name stayed absent
+                continue
+            try:
+                if fresh_only and os.path.getmtime(target) < _T_START - 10.0:
+                    continue
+                with open(target, "rb") as f:
+                    uid = f.read()
+                if len(uid) > 0:
+                    return uid
+            except OSError:
+                pass
         if time.monotonic() > deadline:
-            raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s")
+            raise TimeoutError(f"rank {rank}: no communicator id at {main} after {timeout:.0f} s")
         time.sleep(0.01)
 
 
 def release_unique_id(rank: int, path: str = None):
     if rank != 0:
         return
-    if path is None:
-        base = os.environ.get("RRT_COMM_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
-        path = os.path.join(base, f"rrt_comm_{_launcher_key()}.id")
-    try:
-        os.unlink(path)
-    except OSError:
-        pass
+    for target in _id_paths(path):
+        if target is not None:
+            try:
+                os.unlink(target)
+            except OSError:
+                pass
 
 
 def init_comm(ctx, rank: int, world_size: int, path: str = None):
@@ -92,8 +114,10 @@ def init_comm(ctx, rank: int, world_size: int, path: str = None):
     from . import _ffi
 
     uid = exchange_unique_id(rank, world_size, _ffi.comm_unique_id, path=path)
-    ctx.comm_init(rank, world_size, uid)
-    release_unique_id(rank, path=path)
+    try:
+        ctx.comm_init(rank, world_size, uid)
+    finally:
+        release_unique_id(rank, path=path)
 
 
 # ---------------------------------------------------------------------------------- slab layout

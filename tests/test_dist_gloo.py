@@ -116,3 +116,26 @@ def test_unique_id_hand_over_between_three_ranks(tmp_path):
     assert multi._launcher_key().split("_")[0] == str(os.getppid())
     with pytest.raises(TimeoutError):
         multi.exchange_unique_id(1, 2, None, path=str(tmp_path / "never.id"), timeout=0.2)
+
+
+def test_unique_id_port_keyed_fallback(tmp_path, monkeypatch):
+    """Ranks that do not share a launcher process still meet through the file named after the rendezvous port; a stale one is
+    ignored."""
+    import time
+
+    monkeypatch.setenv("RRT_COMM_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "45678")
+    uid = multi.exchange_unique_id(0, 2, lambda: bytes(range(128)))
+    main, fallback = multi._id_paths(None)
+    assert os.path.exists(main) and os.path.exists(fallback)
+    monkeypatch.setattr(multi, "_launcher_key", lambda: "another_parent")  # rank 1 was started by someone else
+    assert multi.exchange_unique_id(1, 2, None, timeout=20.0) == uid
+    old = time.time() - 3600
+    os.utime(fallback, (old, old))  # a file a crashed run left behind an hour ago
+    with pytest.raises(TimeoutError):
+        multi.exchange_unique_id(1, 2, None, timeout=4.0)
+    monkeypatch.undo()
+    monkeypatch.setenv("RRT_COMM_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "45678")
+    multi.release_unique_id(0)
+    assert not os.path.exists(main) and not os.path.exists(fallback)
