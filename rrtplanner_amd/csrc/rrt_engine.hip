@@ -429,6 +429,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         }
     }
     b->lds_chunks = chunks < 1 ? 1 : (chunks > MAX_LDS_CHUNKS ? MAX_LDS_CHUNKS : chunks);
+    if ((flags & RRT_FLAG_DUBINS) && b->lds_chunks > 5) b->lds_chunks = 5;  // the Dubins kernel keeps the packed near set (36 KiB) in LDS too
     b->h_desc.assign((size_t)Q, QDesc{});
     for (auto &d : b->h_desc) d.status = ST_IDLE;
     const size_t q = (size_t)Q;
@@ -722,12 +723,14 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         return RRT_OK;
     }
     const size_t lds = expand_lds_bytes(b->lds_chunks);
-    const size_t lds_static = (size_t)NWAVE * WCAP * sizeof(uint2) + 2 * NWAVE * (sizeof(Slot) + sizeof(BSlot));
-    if ((int)(lds + lds_static) > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds + lds_static, ctx->max_lds);
     typedef void (*serial_kernel_fn)(BatchView);
     const serial_kernel_fn kern = (b->flags & RRT_FLAG_DUBINS)  ? static_cast<serial_kernel_fn>(rrt_expand_kernel<false, true>)
                                   : (b->flags & RRT_FLAG_REWIRE) ? static_cast<serial_kernel_fn>(rrt_expand_kernel<true, false>)
                                                                  : static_cast<serial_kernel_fn>(rrt_expand_kernel<false, false>);
+    hipFuncAttributes fa{};
+    HIPCHK(ctx, hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
+    const size_t lds_static = fa.sharedSizeBytes;
+    if ((int)(lds + lds_static) > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds + lds_static, ctx->max_lds);
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));

@@ -352,6 +352,16 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
     __shared__ __attribute__((aligned(16))) Slot slots[2 * NWAVE];
     __shared__ __attribute__((aligned(16))) BSlot bslots[2 * NWAVE];
     __shared__ uint32_t rw_cnt[2];  // RW: re-parented nodes of this insertion / fill of the next propagation frontier
+    // DUB: the near set of the iteration packed over all waves (cost through each entry, its node), the waves' scan results, and
+    // what the wave that tests the nearest node found
+    constexpr int PKCAP = DUB ? NWAVE * WCAP : 1;
+    __shared__ __attribute__((aligned(16))) double pk_cost[PKCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t pk_idx[PKCAP];
+    __shared__ __attribute__((aligned(16))) u32x4 dub_slot[2 * NWAVE];
+    __shared__ struct {
+        double cost;
+        uint32_t ok, cells;
+    } dub_nn;
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     const int q = (int)blockIdx.x;
     QDesc *D = bv.desc + q;
@@ -541,6 +551,143 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         }
         STAMP(0);
 
+        uint32_t vbest = NONE;
+        double cbest = 0.0;
+        bool fast_done = false;
+        if (DUB) {
+            // ---------------- Dubins: a word evaluation costs ~1150 f64 operations, so nothing is evaluated speculatively or twice.
+            // The waves' near-set lists are priced as ONE packed list (64 live lanes per wave instead of each wave's dozen),
+            // the nearest node's word is evaluated and swept once (by the last wave, meanwhile), and candidates are tested in
+            // global (cost, index) order, the two cheapest per round by two waves on two SIMDs. ----------------
+            if (lane == 0) dub_slot[par * NWAVE + wave] = u32x4{kd, ki, wcnt, 0u};
+            __syncthreads();  // the scan results of all waves; last iteration's node is visible
+            u32x4 ds = {NONE, NONE, 0u, 0u};
+            if (lane < NWAVE) ds = dub_slot[par * NWAVE + lane];
+            uint32_t d2n = ds.x, vn = ds.y;
+            wave_min_key_idx(d2n, vn);
+            uint32_t incl = ds.z;  // prefix sum of the waves' list lengths over lanes 0..15 (one DPP row)
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
+            const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, NWAVE - 1);
+            const uint32_t woff = lane < NWAVE ? incl - ds.z : NONE;  // exclusive; lanes past the waves never own an entry
+            if (__ballot(lane < NWAVE && ds.z > (uint32_t)WCAP) == 0) {  // (a list that overflowed its LDS part: the general path below)
+                fast_done = true;
+                for (uint32_t g0 = (uint32_t)wave * 64u; g0 < T; g0 += TPB) {  // (wave-uniform trip count: the bisection reads lanes 0..15 of every wave)
+                    const uint32_t g = g0 + (uint32_t)lane;  // entry g of the packed list: owner = the largest wave w with woff[w] <= g
+                    uint32_t lo = 0;
+#pragma unroll
+                    for (uint32_t bit = 8; bit != 0; bit >>= 1) {
+                        const uint32_t cand = lo + bit;
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cand << 2), (int)woff);
+                        lo = v <= g ? cand : lo;
+                    }
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)woff);
+                    if (g < T) {
+                        const u32x2 e = ((RRT_LDS u32x2 *)wlist_lds)[lo * WCAP + (g - base)];  // {node, d2}
+                        pk_idx[g] = e.x;
+                        pk_cost[g] = node_cost(e.x) + dub_between_dev(node_xy(e.x), node_h(e.x), xq, hq, dc).len;
+                    }
+                }
+                if (wave == NWAVE - 1) {  // the nearest node: its word, the cost through it, its sweep (rrt.py:422-424)
+                    const uint32_t a = node_xy(vn);
+                    const int ha = node_h(vn);
+                    const dub_path_t pth = dub_between_dev(a, ha, xq, hq, dc);
+                    int cc = 0;
+                    const bool ok = dub_sweep_wave(og, dc, a, ha, xq, pth, lane, cc);
+                    if (lane == 0) {
+                        dub_nn.cost = node_cost(vn) + pth.len;
+                        dub_nn.ok = ok ? 1u : 0u;
+                        dub_nn.cells = (uint32_t)cc;
+                    }
+                }
+                __syncthreads();
+                const bool nocoll = dub_nn.ok != 0u;
+                const int cells = (int)dub_nn.cells;
+                const double cnear = dub_nn.cost;
+                const bool dup = ((bm_word >> (cell & 31)) & 1u) || (pend_valid && pend == xq);
+                const bool acc = nocoll && !dup && j != n;  // rrt.py:425
+                sum_j += (unsigned long long)j;
+                sum_cells_nn += (unsigned long long)cells;
+                if (logs && t == 0) {
+                    bv.nearest_log[(size_t)q * bv.n_cap + i] = (int32_t)vn;
+                    bv.accept_log[(size_t)q * bv.n_cap + i] = (uint8_t)acc;
+                    bv.cbest_log[(size_t)q * bv.n_cap + i] = clog;
+                    bv.j_log[(size_t)q * bv.n_cap + i] = j;
+                }
+                if (!acc) {
+                    pend_valid = false;
+                    STAMP(3);
+                    continue;
+                }
+                vbest = vn;
+                cbest = cnear;
+                if (star) {  // choose parent (rrt.py:511-521): the first entry in (cost, index) order below cnear whose sweep is free
+                    sum_near += (unsigned long long)T;
+                    double lbc = -1.0;
+                    uint32_t lbi = 0;
+                    for (int round = 0;; ++round) {
+                        Top2 tt;  // this thread's share of the packed list, at or above the lower bound
+                        tt.init();
+                        for (uint32_t g = (uint32_t)t; g < T; g += TPB) {
+                            const double c = pk_cost[g];
+                            const uint32_t ix = pk_idx[g];
+                            if (c < cnear && !key_lt(c, ix, lbc, lbi)) tt.fold(c, ix);
+                        }
+                        tt.wave_reduce();
+                        BSlot bs;
+                        bs.pc = tt.c1;
+                        bs.pi = tt.i1;
+                        bs.uc = tt.c2;
+                        bs.ui = tt.i2;
+                        bs.cells = bs.tested = 0;
+                        if (lane == 0) bslots[(round & 1) * NWAVE + wave] = bs;
+                        __syncthreads();
+                        Top2 gt;  // the two cheapest of all: lane w folds wave w's two, then the wave reduces
+                        gt.init();
+                        if (lane < NWAVE) {
+                            const BSlot r = bslots[(round & 1) * NWAVE + lane];
+                            if (r.pi != NONE) gt.fold(r.pc, r.pi);
+                            if (r.ui != NONE) gt.fold(r.uc, r.ui);
+                        }
+                        gt.wave_reduce();
+                        if (gt.i1 == NONE) break;  // no entry left below cnear: the nearest stays the parent
+                        if (wave < 2) {  // waves 0 and 1 (two SIMDs) test the two, both tests in flight side by side
+                            const uint32_t cand = wave == 0 ? gt.i1 : gt.i2;
+                            uint32_t res = 0;
+                            if (cand != NONE) {
+                                int cc = 0;
+                                const bool ok = edge_free(cand, cc);  // rrt.py:519
+                                res = (ok ? 0x80000000u : 0u) | (uint32_t)cc;
+                            }
+                            if (lane == 0) dub_slot[2 * NWAVE - 2 + wave].w = res;  // (the .w words of the last two slots are free)
+                        }
+                        __syncthreads();
+                        const uint32_t r1 = dub_slot[2 * NWAVE - 2].w, r2_ = dub_slot[2 * NWAVE - 1].w;
+                        n_los_cand += 1;
+                        sum_cells_cand += (unsigned long long)(r1 & 0x7fffffffu);
+                        if (r1 >> 31) {
+                            vbest = gt.i1;
+                            cbest = gt.c1;
+                            break;
+                        }
+                        if (gt.i2 == NONE) break;
+                        n_los_cand += 1;  // (the second test counts only when the first failed, as in the sequential order)
+                        sum_cells_cand += (unsigned long long)(r2_ & 0x7fffffffu);
+                        if (r2_ >> 31) {
+                            vbest = gt.i2;
+                            cbest = gt.c2;
+                            break;
+                        }
+                        lbc = gt.c2;
+                        lbi = gt.i2 + 1;
+                        __syncthreads();  // (the result words are rewritten next round)
+                    }
+                }
+            }
+        }
+        if (!fast_done) {
         // ---------------- A': speculative work of this wave, overlapping the other waves' scans ----------------
         // (a) local nearest: its cost and its line of sight to the sample
         uint32_t my_nn_los = 0;
@@ -646,8 +793,8 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
         }
 
         // ---------------- C: choose parent (rrt.py:511-521) ----------------
-        uint32_t vbest = vn;
-        double cbest = DUB ? vc_near : vc_near + sqrt_u32(d2n);
+        vbest = vn;
+        cbest = DUB ? vc_near : vc_near + sqrt_u32(d2n);
         if (star) {
             const double cnear = cbest;
             sum_near += (unsigned long long)wave_sum_u32(s.wcnt);
@@ -727,6 +874,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                 cbest = pc;
             }
         }
+        }  // !fast_done
         STAMP(3);
 
         // ---------------- D: insert (rrt.py:524-529); rewire scan :531-546 is vacuous ----------------
