@@ -30,7 +30,6 @@
 namespace rrtdev {
 
 constexpr int BS = 16;  // most samples one workgroup resolves per pass (see BSM below)
-constexpr int CG = 2;   // cells whose records an owner streams concurrently
 
 // ---- teams: G workgroups (CUs) on one query ---------------------------------------------------------------------
 // A single query is a chain of inserts, but the expensive parts of a block -- scan and owner phase -- only read the
@@ -257,6 +256,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     static_assert(PIPE == (ROLE != ROLE_ALL), "roles are the halves of a pipelined team");
     constexpr int LAG = PipeShape<PIPE, INF>::LAG, NP = PipeShape<PIPE, INF>::NP, NSLOT = PipeShape<PIPE, INF>::NSLOT;
     constexpr int SB = BSM * G;  // samples per (super-)block: one lane of the committing wave each; BSM per member
+    // steps (of 64 records) of the near-set stream a wave has in flight: two where one wave streams a sample's whole ball, one
+    // where a group of waves shares it (a wave of a group rarely has a second step, and the team kernels sit at the register cap:
+    // measured, profiles/r02_experiments.md)
+    constexpr int CG = (BSM == 16) ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
     auto &nnx = L.nnx;
     auto &brec = L.brec;
@@ -415,13 +418,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         const int ny = cy1 - cy0 + 1, ncr = (cx1 - cx0 + 1) * ny;
         const float boundf = screen_of(bound);
         const uint32_t boundhi = hi_of(bound);  // vcost >= bound  <=>  its high word > boundhi or (== and ...): `<=` keeps a superset
-        // the cells of the ball's bounding box: lane c (< ncr, first 64) holds cell c's fill count and record offset
-        uint32_t tcnt = 0, toff = 0;
-        if (lane < ncr) {
-            const int cell = (cx0 + lane / ny) * ncy + (cy0 + lane % ny);
-            tcnt = cellcnt[cell];
-            toff = (uint32_t)cell * (uint32_t)ccap;
-        }
         tt.init();
         float m1 = FINF, m2 = FINF;  // this lane's two cheapest verified entries, rounded up to f32
         uint32_t hits = 0;
@@ -474,11 +470,18 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             T = w2 < boundf ? w2 : boundf;
             Thi = hi_of((double)T);
         };
-        if (ncr <= 64) {
-            // The records of all touched cells as ONE stream: lane l of a step takes record 64 * step + l of the concatenation of
-            // the cells' arrays, so a step is 64 live records whatever the fill of the single cells (a cell holds 10 - 30 nodes
-            // at these densities: cell by cell three lanes in four would idle).  Exclusive prefix sum of the fill counts over the
-            // lanes; a lane finds its cell by bisection over that prefix (ds_bpermute: the prefix stays in registers).
+        // The records of all touched cells as ONE stream: lane l of a step takes record 64 * step + l of the concatenation of
+        // the cells' arrays, so a step is 64 live records whatever the fill of the single cells (a cell holds 10 - 30 nodes
+        // at these densities: cell by cell three lanes in four would idle).  Exclusive prefix sum of the fill counts over the
+        // lanes; a lane finds its cell by bisection over that prefix (ds_bpermute: the prefix stays in registers).  The cells of
+        // the ball's bounding box are taken 64 at a time (one slab unless the radius is far beyond the cell size).
+        for (int cbase = 0; cbase < ncr; cbase += 64) {
+            uint32_t tcnt = 0, toff = 0;  // lane c: fill count and record offset of cell cbase + c
+            if (cbase + lane < ncr) {
+                const int ci = cbase + lane, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
+                tcnt = cellcnt[cell];
+                toff = (uint32_t)cell * (uint32_t)ccap;
+            }
             uint32_t incl = tcnt;
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
@@ -515,43 +518,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 if (dirty) tighten();
             }
-        } else {
-        for (int c0 = part * CG; c0 < ncr; c0 += nparts * CG) {  // more than 64 cells (a radius far beyond the cell size): cell by cell, CG at a time
-            uint32_t cnt[CG];
-            const u32x4 *rec[CG];
-            uint32_t maxc = 0;
-#pragma unroll
-            for (int g2 = 0; g2 < CG; ++g2) {
-                cnt[g2] = 0;
-                rec[g2] = cellrec;
-                if (c0 + g2 < ncr) {
-                    if (c0 + g2 < 64) {
-                        cnt[g2] = (uint32_t)__builtin_amdgcn_readlane((int)tcnt, c0 + g2);
-                        rec[g2] = cellrec + (uint32_t)__builtin_amdgcn_readlane((int)toff, c0 + g2);
-                    } else {
-                        const int ci = c0 + g2, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
-                        cnt[g2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cellcnt[cell]);
-                        rec[g2] = cellrec + (size_t)cell * (size_t)ccap;
-                    }
-                }
-                maxc = cnt[g2] > maxc ? cnt[g2] : maxc;
-            }
-            for (uint32_t s0 = 0; s0 < maxc; s0 += 64) {
-                const uint32_t s = s0 + (uint32_t)lane;
-                u32x4 rc[CG];
-                // unconditional loads (a clamped slot of the same cell; every cell array has at least one slot) so that
-                // all CG loads are issued back to back; lanes past the fill count get a far-away point afterwards
-#pragma unroll
-                for (int g2 = 0; g2 < CG; ++g2) rc[g2] = rec[g2][s < cnt[g2] ? s : 0u];  // {xy, index, vcost}
-#pragma unroll
-                for (int g2 = 0; g2 < CG; ++g2)
-                    if (!(s < cnt[g2])) rc[g2].x = 0x7fff7fffu;  // never within the radius
-                bool dirty = false;
-#pragma unroll
-                for (int g2 = 0; g2 < CG; ++g2) eval_record(rc[g2], dirty);
-                if (dirty) tighten();
-            }
-        }
         }
         nnear_part = wave_sum_u32(hits);
         tt.wave_reduce();
