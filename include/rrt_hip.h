@@ -75,6 +75,9 @@ typedef struct rrt_query {
     int32_t nh;              /* number of discrete headings, 1 .. 256 */
     int32_t hs, hg;          /* heading index of the start / goal pose */
     int32_t pad_;
+    /* optional: the same samples already packed, x | y << 16 per sample (n words).  When non-NULL it is used instead of
+     * `samples` (which may then be NULL): a host that keeps its free cells packed saves the (n,2) int64 gather of rrt.py:240 */
+    const uint32_t *samples_packed;
 } rrt_query;
 
 /* Result of one query: the arrays plan() hands to build_graph (rrt.py:334-369).

@@ -75,6 +75,7 @@ class Query(C.Structure):
         ("samples", C.c_void_p),
         ("C", C.c_double * 4),
         ("headings", C.c_void_p), ("rho", C.c_double), ("nh", C.c_int32), ("hs", C.c_int32), ("hg", C.c_int32), ("pad_", C.c_int32),
+        ("samples_packed", C.c_void_p),
     ]
 
 
@@ -198,15 +199,19 @@ class ResultArrays:
 def make_query(alg, n, xs, xg, samples, r2_rewire=0, goal_d2=0, Cmat=None, headings=None, rho=0.0, nh=0):
     """Build an rrt_query; returns (Query, keepalive).  Dubins queries (alg 3 / 4): xs / xg are (x, y, heading index),
     `headings` the heading index of every sample, rho the turning radius in cells, nh the number of headings."""
-    s = np.ascontiguousarray(samples, dtype=np.int32)
-    if s.shape != (n, 2):
-        raise ValueError(f"samples must have shape ({n}, 2), got {s.shape}")
     q = Query()
+    if isinstance(samples, np.ndarray) and samples.dtype == np.uint32 and samples.shape == (n,):
+        s = np.ascontiguousarray(samples)  # already packed: x | y << 16
+        q.samples_packed = s.ctypes.data
+    else:
+        s = np.ascontiguousarray(samples, dtype=np.int32)
+        if s.shape != (n, 2):
+            raise ValueError(f"samples must have shape ({n}, 2), got {s.shape}")
+        q.samples = s.ctypes.data
     q.alg, q.n = int(alg), int(n)
     q.xs[0], q.xs[1] = int(xs[0]), int(xs[1])
     q.xg[0], q.xg[1] = int(xg[0]), int(xg[1])
     q.r2_rewire, q.goal_d2 = int(r2_rewire), int(goal_d2)
-    q.samples = s.ctypes.data
     if Cmat is not None:
         cm = np.asarray(Cmat, dtype=np.float64).reshape(4)
         for k in range(4):

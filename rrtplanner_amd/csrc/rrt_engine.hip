@@ -525,11 +525,18 @@ extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu)
     if (qu->xs[0] < 0 || qu->xs[0] >= W || qu->xs[1] < 0 || qu->xs[1] >= H || qu->xg[0] < 0 || qu->xg[0] >= W ||
         qu->xg[1] < 0 || qu->xg[1] >= H)
         return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: start/goal outside the %dx%d grid", W, H);
-    if (!qu->samples) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: samples is NULL");
+    if (!qu->samples && !qu->samples_packed) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: samples is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     b->stage.resize((size_t)qu->n);
     for (int k = 0; k < qu->n; ++k) {
-        const int x = qu->samples[2 * k], y = qu->samples[2 * k + 1];
+        int x, y;
+        if (qu->samples_packed) {
+            x = (int)(qu->samples_packed[k] & 0xffffu);
+            y = (int)(qu->samples_packed[k] >> 16);
+        } else {
+            x = qu->samples[2 * k];
+            y = qu->samples[2 * k + 1];
+        }
         if (x < 0 || x >= W || y < 0 || y >= H) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: sample %d outside the grid", k);
         b->stage[(size_t)k] = ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16);
     }

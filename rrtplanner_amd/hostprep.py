@@ -58,6 +58,18 @@ def draw_free_samples(rand_gen: np.random.Generator, free: np.ndarray, count: in
     return np.ascontiguousarray(free[idx], dtype=np.int64)
 
 
+def pack_cells(cells: np.ndarray) -> np.ndarray:
+    """(F,2) integer cells -> uint32 x | y << 16 (the device's node / sample format; grids are at most 2048 wide)."""
+    c = np.asarray(cells)
+    return np.ascontiguousarray(c[:, 0].astype(np.uint32) | (c[:, 1].astype(np.uint32) << np.uint32(16)))
+
+
+def draw_free_samples_packed(rand_gen: np.random.Generator, free_packed: np.ndarray, count: int) -> np.ndarray:
+    """draw_free_samples on the packed free-cell table: the same `count` draws from the generator (one call), a 4-byte gather
+    instead of the (count, 2) int64 one."""
+    return free_packed[rand_gen.choice(free_packed.shape[0], size=count)]
+
+
 def draw_unitball(rand_gen: np.random.Generator, count: int) -> np.ndarray:
     """`count` consecutive unit-ball points (rrt.py:579-587): r = U(0,1), theta = 2*pi*U(0,1),
     (sqrt(r)cos(theta), sqrt(r)sin(theta)).  One uniform block == 2*count scalar draws."""

@@ -284,7 +284,9 @@ class RRT(object):
         ctx = self._device()
         bitgen = self.rand_gen.bit_generator
         state0 = bitgen.state
-        samples = hostprep.draw_free_samples(self.rand_gen, self.free, n)  # n draws, as rrt.py:421/502/696
+        if getattr(self, "_free_packed_of", None) is not self.free:  # (free is replaced, never edited in place: set_og / set_og_resident)
+            self._free_packed, self._free_packed_of = hostprep.pack_cells(self.free), self.free
+        samples = hostprep.draw_free_samples_packed(self.rand_gen, self._free_packed, n)  # n draws, as rrt.py:421/502/696
         Cm = None
         if alg == _ffi.ALG_INFORMED:
             try:
@@ -309,7 +311,7 @@ class RRT(object):
             # unit-ball stream for the remaining iterations and resume on the device.
             i_sw = res.i_switch
             bitgen.state = state0
-            hostprep.draw_free_samples(self.rand_gen, self.free, i_sw)
+            hostprep.draw_free_samples_packed(self.rand_gen, self._free_packed, i_sw)
             if Cm is None:
                 hostprep.rotation_to_world_frame(xs, xg)  # raises like rrt.py:609-612 would
                 raise np.linalg.LinAlgError("rotation_to_world_frame is not finite (xstart == xgoal?)")

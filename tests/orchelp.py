@@ -46,7 +46,11 @@ def golden(name):
 
 def query_fields(query):
     n = query.n
-    samples = np.ctypeslib.as_array(C.cast(query.samples, C.POINTER(C.c_int32)), shape=(n, 2)).copy()
+    if query.samples_packed:
+        pk = np.ctypeslib.as_array(C.cast(query.samples_packed, C.POINTER(C.c_uint32)), shape=(n,))
+        samples = np.stack([pk & 0xffff, pk >> 16], axis=1).astype(np.int32)
+    else:
+        samples = np.ctypeslib.as_array(C.cast(query.samples, C.POINTER(C.c_int32)), shape=(n, 2)).copy()
     return dict(alg=query.alg, n=n, xs=(query.xs[0], query.xs[1]), xg=(query.xg[0], query.xg[1]),
                 r2_rewire=query.r2_rewire, goal_d2=query.goal_d2, samples=samples,
                 Cmat=np.array([query.C[k] for k in range(4)]))
