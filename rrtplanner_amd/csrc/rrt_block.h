@@ -5,17 +5,21 @@
 // dependencies between samples of one block are resolved afterwards in sample order.  The result is bit-identical to the
 // sequential loop.  A team of G workgroups (one per CU) shares the block: member g takes BSM samples (see "teams" below).
 //
-//   A  scan (all 16 waves of every member): every lane loads 4 nodes (16 bytes) once and evaluates them against the member's
-//      samples held in scalar registers: coordinates pre-scaled by 16 make v_dot2_i32_i16(d, d, tag) = 256*d2 + tag the packed
-//      nearest-neighbour key in ONE instruction (brute force over the whole live tree, near :150-155).
+//   A  scan (all 16 waves of every member; RRTStandard, and RRT* with r_rewire < 16): every lane loads 4 nodes (16 bytes) once
+//      and evaluates them against the member's samples held in scalar registers: coordinates pre-scaled by 16 make
+//      v_dot2_i32_i16(d, d, tag) = 256*d2 + tag the packed nearest-neighbour key in ONE instruction (brute force over the whole
+//      live tree, near :150-155).
 //      -- barrier --
-//   B  owner phase: one wave (or a group of 2..16 waves) per sample.  It folds the 16 per-wave minima (lowest index on
-//      ties), tests the line of sight snapshot-nearest -> sample and reads the `sampled` bit (rrt.py:424-425).
+//   B  owner phase: one wave (or a group of 2..16 waves) per sample.
 //      RRT*: the radius-ball near set (within :176-181) comes from a uniform cell grid over the map: every tree node also
 //      lives as a 16-byte record {xy, index, vcost} in the array of its cell, so the owners stream the records of the cells
-//      the ball touches (coalesced 16-byte loads, no gathers), price them (vcost + sqrt(d2)) and find the first entry in
-//      (cost, index) order with cost < cost-via-nearest and a free line of sight (choose parent :511-521).  vcost never
-//      changes after the insert (the rewire predicate :536 is never true), so the copy in the record stays valid.
+//      the ball touches as one packed stream (64 live records per step, coalesced 16-byte loads), price them
+//      (vcost + sqrt(d2)) and find the first entry in (cost, index) order with cost < cost-via-nearest and a free line of sight
+//      (choose parent :511-521).  The nearest node comes out of the same stream -- a hit lies inside the ball, everything outside
+//      the streamed cells is farther -- so phase A does not run for these queries; a sample whose ball is empty gets its nearest
+//      from one wave's own pass over the node cache.  vcost never changes after the insert (the rewire predicate :536 is never
+//      true), so the copy in the record stays valid.
+//      Then: the line of sight nearest -> sample and the `sampled` bit (rrt.py:424-425).
 //      -- barrier; members g > 0 hand their records to member 0 --
 //   C  commit (wave 0 of member 0, one lane per sample): samples whose result cannot be changed by an earlier sample of the
 //      same block (none inserted that is nearer than the snapshot nearest, on the same cell, or a candidate parent that
@@ -44,8 +48,8 @@ constexpr int BS = 16;  // most samples one workgroup resolves per pass (see BSM
 //   commit    member 0 -> members g>0: plain stores (nodes, costs, parents, cell records, bitmap), agent release,
 //             s_waitcnt, flag; a member polls the flag with one wave, runs ONE agent acquire (drops its L1), waits for it,
 //             joins the workgroup barrier, and only then the workgroup loads.
-// Teams of 8 and more are pipelined (template parameter PIPE below): one more workgroup that only commits, the workers one
-// block ahead of it.  All members must be resident together (the launch keeps teams x members <= CUs); every spin is bounded
+// Teams can be pipelined (template parameter PIPE below; instantiated for 2, 3, 4, 8, 16, 32 and 64 workers): one more workgroup
+// that only commits, the workers two blocks ahead of it.  All members must be resident together (the launch keeps teams x members <= CUs); every spin is bounded
 // by a wall-clock limit that fails the query (status ST_TEAM_FAIL, the host then continues it with one CU) instead of
 // hanging the device.
 constexpr int TEAM_MAX = 64;
