@@ -26,7 +26,8 @@ for q in range(a.queries):
                               Cmat=hostprep.rotation_to_world_frame(xs, xg)))
 ref = None
 bad = 0
-for team, pipe in ((None, True), (None, False), (32, True), (16, True), (16, False), (8, True), (4, True), (2, True), (1, True)):
+for team, pipe in ((None, True), (None, False), (32, True), (16, True), (16, False), (8, True), (4, True), (4, False), (3, True), (2, True), (2, False),
+                   (1, True)):
     b = _ffi.Batch(ctx, a.queries, a.n, team=team, pipe=pipe)
     for q, (qu, keep) in enumerate(qs):
         b.set_query(q, qu)
