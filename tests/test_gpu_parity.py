@@ -595,6 +595,30 @@ def test_every_team_size_gives_the_same_trees_every_time(gpu_ctx):
         b.close()
 
 
+def test_maximum_capacity_on_the_largest_grid(gpu_ctx):
+    """The limits of this path: n = 262143 samples on a 2048 x 2048 grid, RRT*, default team -- node indices use
+    all 18 bits, the scan key all 64 chunk tags, squared distances all 23 bits.  Whole tree equal to the oracle's; one sample
+    more is refused.  (tools/big_case.py runs the other planners and one CU at this size.)"""
+    og = perlin_occupancygrid(2048, 2048, seed=3)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    xs, xg = random_connected_pair(og, np.random.default_rng(11))
+    n = 262143
+    samples = hostprep.draw_free_samples(np.random.default_rng(5), np.argwhere(og8 == 0), n)
+    r2 = hostprep.radius_threshold(64)
+    q, keep = _ffi.make_query(1, n, xs, xg, samples, r2_rewire=r2)
+    rc, res = gpu_ctx.plan(q, n)
+    st, ro = oracle.plan(og8, n, 1, xs, xg, samples, r2_rewire=r2, logs=False)
+    live = ro.j + (1 if ro.found else 0)
+    assert rc == st and res.j == ro.j and res.vgoal == ro.vgoal and ro.j > 250000
+    assert np.array_equal(res.pts[:live], ro.pts[:live]) and np.array_equal(res.parent[:live], ro.parent[:live])
+    assert np.array_equal(res.vcost[:live], ro.vcost[:live])
+    assert res.sum_j == ro.sum_j and res.sum_near == ro.sum_near
+    with pytest.raises(_ffi.RRTError) as e:
+        _ffi.Batch(gpu_ctx, 1, n + 1)
+    assert e.value.code == _ffi.RRT_E_UNSUPPORTED
+
+
 # ------------------------------------------------------------------------------- properties at full size
 def test_full_size_properties_rrtstar_1024_n50000():
     """BASELINE config 2 (RRT*, 1024x1024, n=50000): size-independent properties of the result --
