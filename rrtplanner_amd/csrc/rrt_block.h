@@ -59,8 +59,17 @@ constexpr int TEAM_MAX = 64;
 #ifndef RRT_PIPE_LAG_INF
 #define RRT_PIPE_LAG_INF 2  // ... when the batch may hold Informed queries (a commit that moves the ellipse voids the blocks in flight)
 #endif
-constexpr int TEAM_BYTES = 36864;                // per query: [go | fail | state | records | arrival flags], 128-byte lines
-constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384 /* 3 x 64 */, TEAM_OFF_REC = 1024 /* 3 x 8192 */, TEAM_OFF_ARRIVE = 25600 /* 65 x 128 */, TEAM_OFF_RES = 33920 /* 65 x 16 */;
+#ifndef RRT_NPMAX
+#define RRT_NPMAX 2  // most blocks in flight a record can carry interaction masks for (>= both RRT_PIPE_LAG values)
+#endif
+constexpr int NPMAX = RRT_NPMAX;
+constexpr int BREC_WORDS = 10 + 3 * NPMAX;       // 8-byte words of an owner's record (BRec below): 128 bytes for two blocks in flight
+// per query: [go | fail | state (NPMAX + 1 slots of 64 bytes) | records (NPMAX + 1 slots of 64) | arrival flags (65 x 128) | go2goal answers (65 x 16)]
+constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384, TEAM_OFF_REC = 1024;
+constexpr int TEAM_OFF_ARRIVE = (TEAM_OFF_REC + (NPMAX + 1) * 64 * BREC_WORDS * 8 + 127) / 128 * 128;
+constexpr int TEAM_OFF_RES = TEAM_OFF_ARRIVE + 65 * 128;
+constexpr int TEAM_BYTES = (TEAM_OFF_RES + 65 * 16 + 1023) / 1024 * 1024;
+static_assert(TEAM_OFF_STATE + (NPMAX + 1) * 64 <= TEAM_OFF_REC, "state slots");
 constexpr unsigned long long TEAM_TIMEOUT_TICKS = 50000000ull;  // 0.5 s of the 100 MHz wall clock
 
 typedef unsigned long long u64;
@@ -155,11 +164,10 @@ struct BRec {
     u64 nnmask;         // earlier samples of the (super-)block strictly nearer than the snapshot nearest
     u64 rmask;          // earlier samples within r_rewire
     u64 dupmask;        // earlier samples on the same cell
-    u64 pnn[2], pr[2], pdup[2];  // pipelined teams: the same three masks against the samples of the previous super-block [0]
+    u64 pnn[NPMAX], pr[NPMAX], pdup[NPMAX];  // pipelined teams: the same three masks against the samples of the previous super-block [0]
                                  // and of the one before it [1] (workers two blocks ahead of the commit)
 };
-constexpr int BREC_WORDS = 16;
-static_assert(sizeof(BRec) == 8 * BREC_WORDS, "BRec must be 128 bytes");
+static_assert(sizeof(BRec) == 8 * BREC_WORDS, "BRec size");
 union BRecWords {
     BRec r;
     u64 w[BREC_WORDS];
@@ -203,11 +211,11 @@ union BlkWords {
 };
 
 struct ParRound {  // pipelined committer: the samples re-resolved side by side, one wave each
-    u64 acc_opt, aprev[2];
+    u64 acc_opt, aprev[NPMAX];
     uint32_t list[NWAVE];
     uint32_t accs[64];  // per sample: inserted by its re-resolution?
     uint32_t count;
-    int32_t jp0[2];
+    int32_t jp0[NPMAX];
 };
 
 // How far the workers run ahead of the commit: two blocks (every record carries masks against the samples of BOTH blocks in
@@ -215,6 +223,7 @@ struct ParRound {  // pipelined committer: the samples re-resolved side by side,
 template <bool PIPE, bool INF>
 struct PipeShape {
     static constexpr int LAG = PIPE ? (INF ? RRT_PIPE_LAG_INF : RRT_PIPE_LAG) : 0;
+    static_assert(LAG <= NPMAX, "a record carries masks for NPMAX blocks in flight");
     static constexpr int NP = LAG > 0 ? LAG : 1;      // previous blocks a record / the commit looks at (array extents)
     static constexpr int NSLOT = PIPE ? LAG + 1 : 1;  // record and state buffers in the hand-off area: by block number modulo NSLOT
 };
@@ -967,7 +976,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const u64 nnmask = __ballot(lane < sidx && dk < d2s);
             const u64 rmask = __ballot(lane < sidx && star && dk < r2);
             const u64 dupmask = __ballot(lane < sidx && xo == Xk);
-            u64 pnn[2] = {0, 0}, pr[2] = {0, 0}, pdup[2] = {0, 0};
+            u64 pnn[NPMAX] = {}, pr[NPMAX] = {}, pdup[NPMAX] = {};
             if (PIPE) {  // ... and every sample of the blocks in flight, which are being committed meanwhile
 #pragma unroll
                 for (int p2 = 0; p2 < NP; ++p2) {
@@ -1013,12 +1022,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 r.nnear = nnear;
                 r.pad = 0;
                 r.pc = pc;
-                r.pnn[0] = pnn[0];
-                r.pnn[1] = pnn[1];
-                r.pr[0] = pr[0];
-                r.pr[1] = pr[1];
-                r.pdup[0] = pdup[0];
-                r.pdup[1] = pdup[1];
+#pragma unroll
+                for (int p2 = 0; p2 < NPMAX; ++p2) {
+                    r.pnn[p2] = pnn[p2];
+                    r.pr[p2] = pr[p2];
+                    r.pdup[p2] = pdup[p2];
+                }
                 brec[0][sidx] = r;
             }
         }
@@ -1049,7 +1058,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             bool free_s = false;
             int cells = 0;
             uint32_t bm_word = 0;
-            u64 nnmask = 0, rmask = 0, dupmask = 0, pnn[2] = {0, 0}, pr[2] = {0, 0}, pdup[2] = {0, 0};
+            u64 nnmask = 0, rmask = 0, dupmask = 0, pnn[NPMAX] = {}, pr[NPMAX] = {}, pdup[NPMAX] = {};
             const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
             uint32_t own_nlist = 0;
             uint32_t vsxy = Xk;
@@ -1239,12 +1248,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 r.nnear = nnear;
                 r.pad = 0;
                 r.pc = pc;
-                r.pnn[0] = pnn[0];
-                r.pnn[1] = pnn[1];
-                r.pr[0] = pr[0];
-                r.pr[1] = pr[1];
-                r.pdup[0] = pdup[0];
-                r.pdup[1] = pdup[1];
+#pragma unroll
+                for (int p2 = 0; p2 < NPMAX; ++p2) {
+                    r.pnn[p2] = pnn[p2];
+                    r.pr[p2] = pr[p2];
+                    r.pdup[p2] = pdup[p2];
+                }
                 brec[0][sidx] = r;
             }
         }
@@ -1420,7 +1429,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         BRec r;
         r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnear = r.pad = 0;
         r.nnmask = r.rmask = r.dupmask = 0;
-        r.pnn[0] = r.pnn[1] = r.pr[0] = r.pr[1] = r.pdup[0] = r.pdup[1] = 0;
+#pragma unroll
+        for (int p2 = 0; p2 < NPMAX; ++p2) r.pnn[p2] = r.pr[p2] = r.pdup[p2] = 0;
         r.Vs = r.cbest = r.pc = 0.0;
         const u64 lbit = 1ull << lane;
         const u64 ltmask = lbit - 1ull;  // lanes below
