@@ -5,7 +5,7 @@
 // dependencies between samples of one block are resolved afterwards in sample order.  The result is bit-identical to the
 // sequential loop.  A team of G workgroups (one per CU) shares the block: member g takes BSM samples (see "teams" below).
 //
-//   A  scan (all 16 waves of every member; RRTStandard, and RRT* with r_rewire < 16): every lane loads 4 nodes (16 bytes) once
+//   A  scan (all 16 waves of every member; RRT* with r_rewire < 16, and RRTStandard on teams of 8 and more): every lane loads 4 nodes (16 bytes) once
 //      and evaluates them against the member's samples held in scalar registers: coordinates pre-scaled by 16 make
 //      v_dot2_i32_i16(d, d, tag) = 256*d2 + tag the packed nearest-neighbour key in ONE instruction (brute force over the whole
 //      live tree, near :150-155).
@@ -345,11 +345,17 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     const int cshift = D->cell_shift, ncy = D->ncy, ccap = D->cell_cap, ncells = D->ncx * D->ncy;
     u32x4 *cellrec = reinterpret_cast<u32x4 *>(bv.cellrec) + (size_t)q * (size_t)bv.rec_stride;
     uint32_t *cellcnt_g = bv.cellcnt + (size_t)q * (size_t)MAX_CELLS;
-    int rad = 0;  // largest |dx| with dx*dx < r2
-    if (r2 > 0) {
-        rad = (r2 >= (1u << 23)) ? 4096 : (int)sqrtf((float)(r2 - 1));
-        while (rad > 0 && (uint32_t)(rad * rad) > r2 - 1) --rad;
-        while ((uint32_t)((rad + 1) * (rad + 1)) <= r2 - 1) ++rad;
+    // The radius of the record stream: r_rewire for RRT* (the near set, within :176-181); for RRTStandard, which has no near set,
+    // two cells -- there the stream only serves the nearest-neighbour search (every tree keeps its nodes in the cell records).
+    // (Only where one wave resolves a sample, i.e. teams of up to 4 workers and single CUs: the many-query shapes.  A single
+    // RRTStandard query on a big team is bound by its committer, which would only pay for the records: measured 5.08 -> 5.27 ms.)
+    const bool cells_on = star || BSM == 16;
+    const uint32_t r2h = star ? r2 : (cells_on ? (uint32_t)((2 << cshift) * (2 << cshift)) : 0u);
+    int rad = 0;  // largest |dx| with dx*dx < r2h
+    if (r2h > 0) {
+        rad = (r2h >= (1u << 23)) ? 4096 : (int)sqrtf((float)(r2h - 1));
+        while (rad > 0 && (uint32_t)(rad * rad) > r2h - 1) --rad;
+        while ((uint32_t)((rad + 1) * (rad + 1)) <= r2h - 1) ++rad;
     }
 
     // ---- LDS carve ----
@@ -441,12 +447,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // one 16-byte record per lane: hit test, parking, the screens and the exact price (rrt.py:176-181, :515-518)
         auto eval_record = [&](const u32x4 rc, bool &dirty) {
             const uint32_t d2 = dist2(rc.x, X);
-            const bool hit = d2 < r2 && (!check_j0 || rc.y < (uint32_t)j0);
+            const bool hit = d2 < r2h && (!check_j0 || rc.y < (uint32_t)j0);
             hits += hit ? 1u : 0u;
             if (hit && (d2 < ld2 || (d2 == ld2 && rc.y < lidx))) {
                 ld2 = d2;
                 lidx = rc.y;
             }
+            if (!star) return;  // RRTStandard: the stream only names the nearest node
             // park everything whose vcost alone can be below the bound (the high word of a non-negative f64 is monotone)
             const bool park = hit && rc.w <= boundhi;
             const unsigned long long pm = __ballot(park);
@@ -677,7 +684,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // the ball holds a node.  The brute-force scan of the node array (phase A) then never runs; a sample whose ball is empty --
     // the first samples of a run, pockets the tree has not reached -- gets its nearest from one wave's own pass over the nodes.
     // Used when the radius spans at least a cell; smaller radii keep phase A (the ball is empty too often).
-    const bool grid_nn = star && rad >= 16;
+    const bool grid_nn = rad >= 16;  // (RRTStandard: always, its stream radius is two cells of at least 16 pixels)
     // what snapshot_parent does behind its stream, for a stream that ran without the bound
     auto finish_parent = [&](uint32_t X, int j0, double bound, Top2 tt, uint32_t nlist, double &pc, uint32_t &pi, uint32_t &ntests, uint32_t &tcells) {
         pc = f64_inf();
@@ -996,8 +1003,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
             if (grid_nn) {
-                nnear = nnear0;
-                if (nnear0 != 0) finish_parent(Xk, j0, cnear_s, tt0, nlist0, pc, pi, ntests, tcells);
+                nnear = star ? nnear0 : 0u;
+                if (star && nnear0 != 0) finish_parent(Xk, j0, cnear_s, tt0, nlist0, pc, pi, ntests, tcells);
             } else if (star) {
                 snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);  // no block node is in the cells yet
             }
@@ -1070,7 +1077,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 vsxy = node_xy(vs);
                 lp = los_issue(og, H, vsxy, Xk, lane);
             }
-            if (star) {
+            if (star || grid_nn) {
                 Top2 tt;
                 tt.init();
                 uint32_t hp = 0, nd2 = NONE, nidx = NONE;
@@ -1330,7 +1337,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
                     const uint32_t Xn = at32(nodes_g, (uint32_t)(j0 + t));
                     if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
-                    if (star) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cells_on) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 j = jn;
                 if (pipe_inf) {
@@ -1415,7 +1422,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
                 const uint32_t Xn = at32(nodes_g, (uint32_t)(j0 + t));
                 if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
-                if (star) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cells_on) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             j = jn;
             __syncthreads();
@@ -1920,7 +1927,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         at32(parent, (uint32_t)jmine) = (int32_t)f.vbest;
                     }
                     atomicOr(&at32(bitmap, cellbit >> 5), 1u << (cellbit & 31));  // rrt.py:426
-                    if (star) {
+                    if (cells_on) {  // the node's cell record: near set of RRT*, nearest-neighbour search
                         const int c = cell_of(xv);
                         const uint32_t slot = __hip_atomic_fetch_add(&cellcnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         u32x4 rc = {xv, (uint32_t)jmine, (uint32_t)cb, (uint32_t)(cb >> 32)};
