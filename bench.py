@@ -232,19 +232,24 @@ def main():
     pairs_local = sum(r.c.sum_j for r in results)
     bad = [r.c.status for r in results if r.c.status not in (0, _ffi.RRT_E_GOAL_UNREACHABLE if dubins else 0)]
     if use_comm:
-        # sanity of the collective: every rank's slab must describe its own queries; this rank's own slab must come back unchanged
+        # sanity of the collective: every rank's slab must describe its own queries; this rank's own slab must come back unchanged.
+        # A failure is counted and summed over the ranks, so that every rank leaves the collectives together before anyone exits.
+        gather_bad = 0
         own = batch.get_result(0)
         back = batch.gather_fetch(rank, 0, n)
         live = own.j + (1 if own.found else 0)
         if (back.j, back.vgoal) != (own.j, own.vgoal) or not (np.array_equal(back.pts[:live], own.pts[:live]) and
                                                               np.array_equal(back.parent[:live], own.parent[:live]) and
                                                               np.array_equal(back.vcost[:live], own.vcost[:live])):
-            raise SystemExit("result gather returned a wrong slab")
+            gather_bad += 1
         far = batch.gather_fetch((rank + 1) % world, Q - 1, n)
         if not (1 <= far.j <= n):
-            raise SystemExit("result gather: a peer's slab does not describe a finished query")
-        agg = ctx.allreduce([nodes_local, iters_local, len(bad)], "sum")
+            gather_bad += 1
+        agg = ctx.allreduce([nodes_local, iters_local, len(bad), gather_bad], "sum")
         nodes_total, iters_total, nbad = float(agg[0]), float(agg[1]), int(agg[2])
+        if int(agg[3]) != 0:
+            ctx.barrier()
+            raise SystemExit(f"result gather returned a wrong slab on {int(agg[3])} check(s) (this rank: {gather_bad})")
     else:
         nodes_total, iters_total, nbad = float(nodes_local), float(iters_local), len(bad)
 

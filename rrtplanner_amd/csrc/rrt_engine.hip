@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -890,7 +891,10 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+std::mutex g_rccl_mutex;  // contexts of different host threads may ask for the library at the same time
+
 int rccl_load(rrt_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle) return RRT_OK;
     void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
