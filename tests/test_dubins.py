@@ -251,3 +251,28 @@ def test_dubins_planner_class_and_batch_on_device(gpu_ctx):
     with pytest.raises(_ffi.RRTError):
         plain.set_query(0, qu)
     plain.close()
+
+
+@pytest.mark.gpu
+def test_plan_batch_with_dubins_queries(gpu_ctx):
+    """rrt_plan_batch picks the Dubins kernel from its first query; a batch that mixes Dubins and straight-line planners is refused."""
+    og, og8, xs, xg, samples, heads = _dub_query(200, 1500, 4)
+    gpu_ctx.set_grid(og8)
+    r2 = hostprep.radius_threshold(24)
+    qs, keep, refs = [], [], []
+    for k, star in enumerate((1, 0, 1)):
+        q, kp = _ffi.make_query(_ffi.ALG_DUBINS_STAR if star else _ffi.ALG_DUBINS, 1500, xs, xg, samples, r2_rewire=r2 if star else 0, headings=heads,
+                                rho=4.0 + k, nh=64)
+        qs.append(q)
+        keep.append(kp)
+        refs.append(oracle.dubins_plan(og8, 1500, star, xs, xg, samples, heads, r2_rewire=r2 if star else 0, rho=4.0 + k, nh=64, logs=False))
+    rc, res = gpu_ctx.plan_batch(qs, [1500] * 3)
+    for r, (st, ro) in zip(res, refs):
+        live = ro.j + (1 if ro.found else 0)
+        assert r.status == st and r.j == ro.j and r.vgoal == ro.vgoal
+        assert np.array_equal(r.parent[:live], ro.parent[:live]) and np.array_equal(r.vcost[:live], ro.vcost[:live])
+    plain, kp = _ffi.make_query(1, 1500, xs[:2], xg[:2], samples, r2_rewire=r2)
+    with pytest.raises(_ffi.RRTError):
+        gpu_ctx.plan_batch([qs[0], plain], [1500, 1500])
+    with pytest.raises(_ffi.RRTError):
+        _ffi.Batch(gpu_ctx, 1, 100, dubins=True, rewire=True)  # the opt-in rewire is not built for the Dubins planners
