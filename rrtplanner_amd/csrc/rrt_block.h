@@ -236,6 +236,7 @@ struct BlockLds {
     alignas(16) BRec brec[PIPE ? 2 : 1][SB];  // (a pipelined committer: this block's records and the next one's)
     uint32_t xq_next[PIPE ? 64 : 1];        // pipelined committer: the next block's samples and whether its records are in
     uint32_t pre_state;
+    uint32_t pubreq;                        // pipelined committer: wave 0 asks wave 3 to raise the go flag of this block
     alignas(16) BSlot bslots[2 * NWAVE];
     alignas(16) BlkState blk;
     alignas(16) unsigned long long statred[SB * 5];
@@ -377,15 +378,32 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     auto &dbg = L.dbg;
     if (t < 16) dbg[t] = 0;
     unsigned long long dbgt = __builtin_amdgcn_s_memtime();
+#ifdef RRT_STAMPS_RS
+#define DBGT(k) \
+    do {        \
+    } while (0)
+#define RST(k)                                                   \
+    do {                                                         \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+        if (t == 0) dbg[k] += now_ - rst_;                       \
+        rst_ = now_;                                             \
+    } while (0)
+#else
 #define DBGT(k)                                                  \
     do {                                                         \
         unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
         if (t == 0) dbg[k] += now_ - dbgt;                       \
         dbgt = now_;                                             \
     } while (0)
+#endif
 #else
 #define DBGT(k) \
     do {        \
+    } while (0)
+#endif
+#ifndef RRT_STAMPS_RS
+#define RST(k) \
+    do {       \
     } while (0)
 #endif
 
@@ -402,6 +420,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         for (int k = t; k < lds_nodes; k += TPB) nodes_lds[k] = (k < j) ? nodes_g[k] : n0;
         for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
         if (t < SB * 5) statred[t] = 0;
+        if (t == 0) L.pubreq = 0;
     }
     __syncthreads();
 
@@ -471,16 +490,14 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (__ballot(maybe) == 0) return;
             if (maybe) {
                 const double cn = V + sqrt_u24(d2);
-                if (cn < bound && !key_lt(cn, rc.y, lbc, lbi)) {  // rrt.py:518, strict
-                    tt.fold(cn, rc.y);
-                    const float cu = screen_of(cn);
-                    if (cu < m1) {
-                        m2 = m1;
-                        m1 = cu;
-                    } else if (cu < m2) {
-                        m2 = cu;
-                    }
-                }
+                const bool in = cn < bound && !key_lt(cn, rc.y, lbc, lbi);  // rrt.py:518, strict
+                if (in) tt.fold(cn, rc.y);
+                // (m1, m2) <- the two smallest of {m1, m2, cu}, without branches: written as conditional assignments the pair
+                // ends up behind a select of addresses and lives in scratch memory, a store and two loads per priced record
+                const float cu = in ? screen_of(cn) : FINF;
+                const float lo = __builtin_fminf(m1, cu), hi = __builtin_fmaxf(m1, cu);
+                m1 = lo;
+                m2 = __builtin_fminf(m2, hi);
             }
             dirty = true;
         };
@@ -789,7 +806,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     bool prefetched = false;  // committer: wave 1 fetched this block's records during the last commit ...
     bool prefetched_smp = false;  // ... and wave 2 its samples (not those of an Informed query: the ellipse may move)
     int bsel = 0;             // committer: which half of brec holds this block's records
-    auto publish_state = [&](uint32_t ep, int32_t flags) {  // wave 0 of member 0: state of block `ep`, then its go flag
+    auto publish_state = [&](uint32_t ep, int32_t flags, bool hand_flag = false) {  // wave 0 of member 0: state of block `ep`, then its go flag
         if (lane == 0) {
             BlkWords u;
             u.b.i = i;
@@ -809,10 +826,25 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // wave 0 made every store of the commit, all of them write-through (nodes, costs, parents, cell records, the bitmap's
         // atomic, the logs' plain stores are host-read only): the flag only must not overtake them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(RRT_EXP_INV_EARLY)
+        asm volatile("buffer_inv sc1" ::: "memory");
+        if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
+#elif defined(RRT_EXP_NO_INV)
+        if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
+        if (!PIPE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#elif defined(RRT_EXP_FLAGWAVE)
+        if (PIPE && hand_flag) {
+            if (lane == 0) __hip_atomic_store(&L.pubreq, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
+            if (!PIPE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+#else
         if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
         // this CU read lines of the arrays just extended through its L1 (the neighbours of the new entries); the stores above
         // bypass it, so drop it like every other member does when it takes the commit
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     };
     while ((pipe_inf && g > 0) || i < n) {
         const int i0 = i, j0 = j;
@@ -1467,6 +1499,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const unsigned long long rs0 = __builtin_amdgcn_s_memtime();
             bool rs_redo = false;
 #endif
+#ifdef RRT_STAMPS_LOS
+            unsigned long long rs_los = 0, rs_nlos = 0;
+#endif
             BRecWords rku;  // the same record in every lane: kept in scalar registers
             rku.r = brec[bsel][k];
 #pragma unroll
@@ -1476,6 +1511,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 rku.w[w] = ((u64)hi << 32) | lo;
             }
             const BRec &rk = rku.r;
+#ifdef RRT_STAMPS_RS
+            unsigned long long rst_ = rs0;
+#endif
+            RST(0);  // record to scalar registers
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
             uint32_t vn = rk.vs, d2n = rk.d2s;
             double Vn = rk.Vs;
@@ -1502,6 +1541,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_k) != 0 || pdup_hit;
             const u64 nm = rk.nnmask & acc_k;
             bool nn_inblock = false;
+            RST(1);  // distances, masks
             if (nm | pany) {  // nearest is an inserted block node: smallest distance, lowest node index on ties (oldest block first)
                 nn_inblock = true;
                 uint32_t bestd = NONE, axy = Xk;
@@ -1530,9 +1570,17 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 d2n = bestd;
                 int cc = 0;
+#ifdef RRT_STAMPS_LOS
+                const unsigned long long l0_ = __builtin_amdgcn_s_memtime();
+#endif
                 nocoll = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:424
+#ifdef RRT_STAMPS_LOS
+                if (__builtin_amdgcn_readfirstlane((int)nocoll) >= 0) rs_los += __builtin_amdgcn_s_memtime() - l0_;
+                rs_nlos += 1;
+#endif
                 cells = (uint32_t)cc;
             }
+            RST(2);  // nearest among block nodes + its line of sight
             acc = nocoll && !dup && !(check_full && j0 + __builtin_popcountll(acc_k) == n);  // rrt.py:425
             uint32_t vbest = vn;
             cbest = Vn + sqrt_u32(d2n);
@@ -1553,6 +1601,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         pi = NONE;
                     }
                 }
+                RST(3);  // cbest, redo decision
                 // inserted block nodes within r_rewire, in (cost, index) order, while they beat the snapshot's best
                 u64 rm = rk.rmask & acc_k;
                 u64 rmp[NP], rmany = rm;
@@ -1595,7 +1644,14 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     for (int p2 = 0; p2 < NP; ++p2)
                         if (set == NP - 1 - p2) axy = (uint32_t)__builtin_amdgcn_readlane((int)xop[p2], (int)kk);
                     int cc = 0;
+#ifdef RRT_STAMPS_LOS
+                    const unsigned long long l0_ = __builtin_amdgcn_s_memtime();
+#endif
                     const bool ok = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:519
+#ifdef RRT_STAMPS_LOS
+                    if (__builtin_amdgcn_readfirstlane((int)ok) >= 0) rs_los += __builtin_amdgcn_s_memtime() - l0_;
+                    rs_nlos += 1;
+#endif
                     ntests += 1;
                     tcells += (uint32_t)cc;
                     if (ok) {
@@ -1615,6 +1671,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     vbest = pi;
                     cbest = pc;
                 }
+                RST(4);  // candidate loop
             }
             if (lane == 0) {  // the final record of this sample (pad = 1: nnear already counts the block's nodes)
                 BRec &f = brec[bsel][k];
@@ -1627,10 +1684,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 f.pad = 1;
                 newcost[k] = cbest;
             }
+            RST(7);  // final record
 #ifdef RRT_STAMPS
             if (t == 0) {
                 dbg[rs_redo ? 10 : 12] += __builtin_amdgcn_s_memtime() - rs0;
                 dbg[rs_redo ? 11 : 5] += 1;
+#ifdef RRT_STAMPS_LOS
+                dbg[14] += rs_los;   // (instead of wave 1's prefetch time)
+                dbg[15] += rs_nlos;  // (instead of wave 0's wait at the end-of-block barrier)
+#endif
             }
 #endif
         };
@@ -1812,7 +1874,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
             if (lane == 0) pre_state = ok ? 1u : 2u;
 #ifdef RRT_STAMPS
+#ifndef RRT_STAMPS_LOS
             if (lane == 0) dbg[14] += __builtin_amdgcn_s_memtime() - pf0;
+#endif
 #endif
         }
         if (PIPE && wave == 2 && pre_smp) {  // (the samples: a wave of their own, one memory round trip less in a row)
@@ -1970,12 +2034,31 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
             // state first (write-through), then everything the commit stored, then the flag
             DBGT(9);
-            if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0);
+            if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0, true);
             DBGT(4);
         }
+#ifdef RRT_EXP_FLAGWAVE
+        if (PIPE && wave == 0 && !remote_ok && lane == 0) __hip_atomic_store(&L.pubreq, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (PIPE && wave == 3) {  // the go flag leaves from a wave that has nothing else in flight: wave 0 never waits for it
+            uint32_t v;
+            for (;;) {
+                v = __hip_atomic_load(&L.pubreq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v != 0u) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) {
+                if (v != 0xffffffffu) __hip_atomic_store(t_go, v, RRT_RLX_AGENT);
+                __hip_atomic_store(&L.pubreq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+#endif
         STAMP(4);
         __syncthreads();
+#ifdef RRT_STAMPS_LOS
+        DBGT(0);  // (slot 15 counts lines of sight in this build)
+#else
         DBGT(15);
+#endif
         {
             const BlkState b = blk;
             if (G > 1 && unis32(b.pad0) != 0) {
