@@ -87,6 +87,29 @@ __device__ __forceinline__ T &at32(T *base, uint32_t idx) {
                                   (size_t)(uint32_t)(idx * (uint32_t)sizeof(T)));
 }
 
+// Loads of tree data that another workgroup of the team has written in this launch (nodes, costs, cell records, the bitmap):
+// agent-scope loads (sc1: past this CU's L1, served by L2 / memory) where COH, so that taking a commit needs no L1 invalidate;
+// plain loads for a query that runs on one CU.
+template <bool COH>
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) {
+    if (COH) return __hip_atomic_load((gu32 *)const_cast<uint32_t *>(p), RRT_RLX_AGENT);
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ double ld_f64(const double *p) {
+    if (COH) return __longlong_as_double((long long)__hip_atomic_load((gu64 *)const_cast<double *>(p), RRT_RLX_AGENT));
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ u32x4 ld_rec(const u32x4 *p) {  // (two 8-byte halves: a record is complete before its go flag is raised)
+    if (COH) {
+        const gu64 *q = (const gu64 *)p;
+        const u64 a = __hip_atomic_load(q, RRT_RLX_AGENT), b = __hip_atomic_load(q + 1, RRT_RLX_AGENT);
+        return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    }
+    return *p;
+}
+
 // A value every lane of the wave holds alike (read from LDS or memory): moved to scalar registers, so that it does not
 // take a vector register per lane for as long as it lives.
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -153,13 +176,13 @@ __device__ __forceinline__ uint32_t key16(uint32_t node_s, uint32_t q_s, uint32_
 struct BRec {
     uint32_t d2s, vs;   // snapshot nearest
     uint32_t los_s;     // line of sight vs -> sample: bit 31 free, low bits cells read
-    uint32_t flags;     // bit 0: cell already in `sampled` at the snapshot
+    uint32_t flags;     // bit 0: cell already in `sampled` at the snapshot; bit 1 (committer's copy): re-resolved, nnear counts the block's nodes
     double Vs;          // vcost[vs]
     double cbest;       // cost of the sample through its snapshot-resolved parent
     uint32_t vbest;     // snapshot-resolved parent (vs, or the best passing near-set entry)
     uint32_t pstat;     // owner's candidate line-of-sight tests: count << 20 | cells
     uint32_t nnear;     // |within| over the snapshot
-    uint32_t pad;
+    float amin;         // no parent below the bound: a lower bound of the cheapest near-set entry at or above it (0: unknown)
     double pc;          // cost of the best passing near-set entry (inf: none, parent is vs)
     u64 nnmask;         // earlier samples of the (super-)block strictly nearer than the snapshot nearest
     u64 rmask;          // earlier samples within r_rewire
@@ -236,7 +259,6 @@ struct BlockLds {
     alignas(16) BRec brec[PIPE ? 2 : 1][SB];  // (a pipelined committer: this block's records and the next one's)
     uint32_t xq_next[PIPE ? 64 : 1];        // pipelined committer: the next block's samples and whether its records are in
     uint32_t pre_state;
-    uint32_t pubreq;                        // pipelined committer: wave 0 asks wave 3 to raise the go flag of this block
     alignas(16) BSlot bslots[2 * NWAVE];
     alignas(16) BlkState blk;
     alignas(16) unsigned long long statred[SB * 5];
@@ -378,32 +400,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     auto &dbg = L.dbg;
     if (t < 16) dbg[t] = 0;
     unsigned long long dbgt = __builtin_amdgcn_s_memtime();
-#ifdef RRT_STAMPS_RS
-#define DBGT(k) \
-    do {        \
-    } while (0)
-#define RST(k)                                                   \
-    do {                                                         \
-        unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
-        if (t == 0) dbg[k] += now_ - rst_;                       \
-        rst_ = now_;                                             \
-    } while (0)
-#else
 #define DBGT(k)                                                  \
     do {                                                         \
         unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
         if (t == 0) dbg[k] += now_ - dbgt;                       \
         dbgt = now_;                                             \
     } while (0)
-#endif
 #else
 #define DBGT(k) \
     do {        \
-    } while (0)
-#endif
-#ifndef RRT_STAMPS_RS
-#define RST(k) \
-    do {       \
     } while (0)
 #endif
 
@@ -411,7 +416,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     const double d2sg = (double)dist2(xs, xg);
     const double C00 = D->C[0], C01 = D->C[1], C10 = D->C[2], C11 = D->C[3];
     double c_ell = 0.0;
-    if (informed && nsoln > 0) c_ell = cmin_soln + sqrt_u32(dist2(xg, nodes_g[vbest_soln]));
+    if (informed && nsoln > 0) c_ell = cmin_soln + sqrt_u24(dist2(xg, nodes_g[vbest_soln]));
 
     // ---- prologue: node cache = live nodes, unfilled slots = copy of node 0 (never nearest: equal distance,
     //      higher index); cell fill counts from HBM ----
@@ -420,11 +425,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         for (int k = t; k < lds_nodes; k += TPB) nodes_lds[k] = (k < j) ? nodes_g[k] : n0;
         for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
         if (t < SB * 5) statred[t] = 0;
-        if (t == 0) L.pubreq = 0;
     }
     __syncthreads();
 
-    auto node_xy = [&](uint32_t v) -> uint32_t { return ((int)v < lds_nodes) ? nodes_lds[v] : nodes_g[v]; };
+    // A team reads whatever its committer stores (nodes, costs, cell records, bitmap) with agent-scope loads: where the nearest node
+    // comes from the record stream (grid_nn, below) no plain load of such bytes is left, and taking a commit costs no L1 invalidate.
+    constexpr bool COH = G > 1;
+    auto node_xy = [&](uint32_t v) -> uint32_t { return ((int)v < lds_nodes) ? nodes_lds[v] : ld_u32<COH>(nodes_g + v); };
     auto cell_of = [&](uint32_t X) -> int { return (ux(X) >> cshift) * ncy + (uy(X) >> cshift); };
 
     // ---- the near set of one sample (within :176-181, choose parent :511-521) ----------------------------------------
@@ -544,7 +551,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
                     const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
                     live[g2] = idx < total;
-                    rc[g2] = cellrec[live[g2] ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}; (record 0 exists: every cell array has a slot)
+                    rc[g2] = ld_rec<COH>(cellrec + (live[g2] ? coff + (idx - cpre) : 0u));  // {xy, index, vcost}; (record 0 exists: every cell array has a slot)
                 }
                 bool dirty = false;
 #pragma unroll
@@ -568,20 +575,29 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // candidates; two per memory round trip made it the straggler of its block:
     // every open entry is tested, one line of sight per LANE.
     // (wc, wi) = the cheapest passing entry; every entry with a key up to it has been tested and holds its cell count.
-    auto consume_list = [&](uint32_t X, double bound, double lbc, uint32_t lbi, uint32_t nlist, double &wc, uint32_t &wi, uint32_t &nval) {
+    // amin: a single-precision lower bound of the cheapest parked entry that is NOT below the bound (+inf: none).
+    auto consume_list = [&](uint32_t X, double bound, double lbc, uint32_t lbi, uint32_t nlist, double &wc, uint32_t &wi, uint32_t &nval,
+                            float &amin) {
         const float boundf = screen_of(bound);
         nval = 0;
         wc = f64_inf();
         wi = NONE;
+        float am = FINF;
         for (uint32_t p0 = 0; p0 < nlist; p0 += 64) {
             const uint32_t p = p0 + (uint32_t)lane;
             u32x4 e = {NONE, 0u, 0u, 0u};
             if (p < nlist) e = clist[p];  // {index, d2, vcost}
             const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
             double cn = f64_inf();
-            if (p < nlist && (float)V + __builtin_amdgcn_sqrtf((float)e.y) < boundf) {
-                const double c = V + sqrt_u24(e.y);
-                if (c < bound && !key_lt(c, e.x, lbc, lbi)) cn = c;
+            if (p < nlist) {
+                const float cf = (float)V + __builtin_amdgcn_sqrtf((float)e.y);
+                bool below = false;  // certainly below the bound (such an entry is open, or one of the tested ones under the lower bound)
+                if (cf < boundf) {
+                    const double c = V + sqrt_u24(e.y);
+                    below = c < bound;
+                    if (below && !key_lt(c, e.x, lbc, lbi)) cn = c;
+                }
+                if (!below) am = __builtin_fminf(am, __builtin_fmaxf(cf * (1.0f - 1.0e-6f) - 4.0e-3f, 0.0f));
             }
             const bool open = cn < bound;
             const unsigned long long om = __ballot(open);
@@ -591,6 +607,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
             nval += (uint32_t)__builtin_popcountll(om);
         }
+        amin = wave_min_f32_nonneg(am);
         if (nval == 0) return;  // every entry was tried
         // one line of sight PER LANE, 64 entries at a time, every open entry tested (each lane walks its own segment, 16 cell
         // loads in flight); the answer is the cheapest passing entry.  (Ranking up to 16 open entries and testing them in
@@ -689,7 +706,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             lbi = tt.i2 + 1;
             if (nlist > clist_cap) continue;  // the list overflowed: stream the cells again above the new lower bound
             uint32_t nval = 0;
-            consume_list(X, bound, lbc, lbi, nlist, pc, pi, nval);
+            float am_;
+            consume_list(X, bound, lbc, lbi, nlist, pc, pi, nval, am_);
             count_tests(clist, nval, pc, pi, ntests, tcells);
             return;
         }
@@ -703,10 +721,18 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // Used when the radius spans at least a cell; smaller radii keep phase A (the ball is empty too often).
     const bool grid_nn = rad >= 16;  // (RRTStandard: always, its stream radius is two cells of at least 16 pixels)
     // what snapshot_parent does behind its stream, for a stream that ran without the bound
-    auto finish_parent = [&](uint32_t X, int j0, double bound, Top2 tt, uint32_t nlist, double &pc, uint32_t &pi, uint32_t &ntests, uint32_t &tcells) {
+    // amin (only meaningful when no parent is found): a lower bound of the cheapest entry at or above the bound -- the stream ran
+    // without the bound, so its two cheapest entries are the two cheapest of the whole ball.  The committer needs it when a node
+    // of a block in flight turns out to be the sample's nearest: the bound moves up, and only an entry between the old bound and
+    // the new one makes it search the ball again.
+    auto lower_f32 = [](double c) -> float { return __builtin_fmaxf((float)c * (1.0f - 1.0e-6f) - 4.0e-3f, 0.0f); };
+    auto finish_parent = [&](uint32_t X, int j0, double bound, Top2 tt, uint32_t nlist, double &pc, uint32_t &pi, uint32_t &ntests, uint32_t &tcells,
+                             float &amin) {
         pc = f64_inf();
         pi = NONE;
+        amin = tt.i1 == NONE ? FINF : lower_f32(tt.c1);
         if (tt.i1 == NONE || !(tt.c1 < bound)) return;  // rrt.py:518, strict
+        amin = tt.i2 == NONE ? FINF : lower_f32(tt.c2);  // (the cheapest entry is below the bound)
         if (tt.i2 != NONE && !(tt.c2 < bound)) tt.i2 = NONE;
         bool ok1, ok2;
         int cc1, cc2;
@@ -726,13 +752,14 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             pi = tt.i2;
             return;
         }
+        amin = 0.0f;  // both are below the bound: unknown unless the parked list tells
         if (nlist > clist_cap) {  // the list overflowed: stream again, bounded, above the two that are blocked
             uint32_t nn2 = 0;
             snapshot_parent(X, j0, false, bound, pc, pi, nn2, ntests, tcells, tt.c2, tt.i2 + 1);
             return;
         }
         uint32_t nval = 0;
-        consume_list(X, bound, tt.c2, tt.i2 + 1, nlist, pc, pi, nval);
+        consume_list(X, bound, tt.c2, tt.i2 + 1, nlist, pc, pi, nval, amin);
         count_tests(clist, nval, pc, pi, ntests, tcells);
     };
     // near()[0] (rrt.py:150-155) of one sample over the snapshot [0, j0) by ONE wave: 256 nodes per step, 4 per lane
@@ -743,7 +770,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (idx0 < j0) {
                 u32x4 v;
                 if (idx0 < lds_nodes) v = nodes_lds4[idx0 >> 2];
-                else v = nodes_g4[idx0 >> 2];
+                else v = ld_rec<COH>(nodes_g4 + (idx0 >> 2));
                 const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -806,7 +833,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     bool prefetched = false;  // committer: wave 1 fetched this block's records during the last commit ...
     bool prefetched_smp = false;  // ... and wave 2 its samples (not those of an Informed query: the ellipse may move)
     int bsel = 0;             // committer: which half of brec holds this block's records
-    auto publish_state = [&](uint32_t ep, int32_t flags, bool hand_flag = false) {  // wave 0 of member 0: state of block `ep`, then its go flag
+    auto publish_state = [&](uint32_t ep, int32_t flags) {  // wave 0 of member 0: state of block `ep`, then its go flag
         if (lane == 0) {
             BlkWords u;
             u.b.i = i;
@@ -826,25 +853,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // wave 0 made every store of the commit, all of them write-through (nodes, costs, parents, cell records, the bitmap's
         // atomic, the logs' plain stores are host-read only): the flag only must not overtake them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if defined(RRT_EXP_INV_EARLY)
-        asm volatile("buffer_inv sc1" ::: "memory");
         if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
-#elif defined(RRT_EXP_NO_INV)
-        if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
-        if (!PIPE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#elif defined(RRT_EXP_FLAGWAVE)
-        if (PIPE && hand_flag) {
-            if (lane == 0) __hip_atomic_store(&L.pubreq, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
-            if (!PIPE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-#else
-        if (lane == 0) __hip_atomic_store(t_go, ep, RRT_RLX_AGENT);
-        // this CU read lines of the arrays just extended through its L1 (the neighbours of the new entries); the stores above
-        // bypass it, so drop it like every other member does when it takes the commit
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+        // this CU read lines of the arrays just extended through its L1 (the neighbours of the new entries: the scan's plain
+        // loads); the stores above bypass it, so drop it like every other member does when it takes the commit
+        if (!grid_nn) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     };
     while ((pipe_inf && g > 0) || i < n) {
         const int i0 = i, j0 = j;
@@ -1004,9 +1016,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 wave_min_key_idx(d2s, vs);
             }
-            const double Vs = at32(vcost, vs);
+            const double Vs = ld_f64<COH>(&at32(vcost, vs));
             const uint32_t cell = (uint32_t)ux(Xk) * (uint32_t)H + (uint32_t)uy(Xk);
-            const uint32_t bm_word = at32(bitmap, cell >> 5);
+            const uint32_t bm_word = ld_u32<COH>(&at32(bitmap, cell >> 5));
             const uint32_t vsxy = node_xy(vs);
             const LosPending lp = los_issue(og, H, vsxy, Xk, lane);  // finished behind the near-set stream
             // earlier samples of this block that could interact once inserted
@@ -1030,13 +1042,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
-            const double cnear_s = Vs + sqrt_u32(d2s);
+            const double cnear_s = Vs + sqrt_u24(d2s);
 #ifdef RRT_STAMPS
             const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
+            float amin = 0.0f;
             if (grid_nn) {
                 nnear = star ? nnear0 : 0u;
-                if (star && nnear0 != 0) finish_parent(Xk, j0, cnear_s, tt0, nlist0, pc, pi, ntests, tcells);
+                amin = FINF;  // (an empty ball)
+                if (star && nnear0 != 0) finish_parent(Xk, j0, cnear_s, tt0, nlist0, pc, pi, ntests, tcells, amin);
             } else if (star) {
                 snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);  // no block node is in the cells yet
             }
@@ -1059,7 +1073,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 r.rmask = rmask;
                 r.dupmask = dupmask;
                 r.nnear = nnear;
-                r.pad = 0;
+                r.amin = amin;
                 r.pc = pc;
 #pragma unroll
                 for (int p2 = 0; p2 < NPMAX; ++p2) {
@@ -1089,11 +1103,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     vs = v.y;
                 }
                 wave_min_key_idx(d2s, vs);
-                Vs = act ? at32(vcost, vs) : 0.0;
-                cnear_s = Vs + sqrt_u32(d2s);
+                Vs = act ? ld_f64<COH>(&at32(vcost, vs)) : 0.0;
+                cnear_s = Vs + sqrt_u24(d2s);
             }
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
+            float amin = 0.0f;  // leader: see finish_parent
             bool free_s = false;
             int cells = 0;
             uint32_t bm_word = 0;
@@ -1105,7 +1120,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             lp.major = 0;
             lp.v = 0;
             if (lead && act && !grid_nn) {  // started here, finished behind the near-set stream
-                bm_word = at32(bitmap, cell >> 5);
+                bm_word = ld_u32<COH>(&at32(bitmap, cell >> 5));
                 vsxy = node_xy(vs);
                 lp = los_issue(og, H, vsxy, Xk, lane);
             }
@@ -1147,9 +1162,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     } else {
                         wave_scan_nearest(Xk, j0, d2s, vs);
                     }
-                    Vs = at32(vcost, vs);
-                    cnear_s = Vs + sqrt_u32(d2s);
-                    bm_word = at32(bitmap, cell >> 5);
+                    Vs = ld_f64<COH>(&at32(vcost, vs));
+                    cnear_s = Vs + sqrt_u24(d2s);
+                    bm_word = ld_u32<COH>(&at32(bitmap, cell >> 5));
                     vsxy = node_xy(vs);
                     lp = los_issue(og, H, vsxy, Xk, lane);
                 }
@@ -1179,13 +1194,21 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #pragma unroll
                     for (int pp = 0; pp < WPS; ++pp) {
                         const GSlot o = gslot[sl * WPS + pp];
-                        if (o.i1 != NONE && o.c1 < cnear_s) tt.fold(o.c1, o.i1);  // (grid_nn: the shares streamed without the bound)
-                        if (o.i2 != NONE && o.c2 < cnear_s) tt.fold(o.c2, o.i2);
+                        if (o.i1 != NONE) tt.fold(o.c1, o.i1);  // (grid_nn: the shares streamed without the bound)
+                        if (o.i2 != NONE) tt.fold(o.c2, o.i2);
                         nnear += o.hits;
                         overflow = overflow || o.nlist > clist_cap;
                     }
+                    // the cheapest entry at or above the bound, where the two cheapest of the ball tell (see finish_parent)
+                    if (grid_nn) amin = (tt.i1 == NONE) ? FINF : !(tt.c1 < cnear_s) ? lower_f32(tt.c1) : (tt.i2 == NONE) ? FINF : !(tt.c2 < cnear_s) ? lower_f32(tt.c2) : 0.0f;
+                    if (tt.i2 != NONE && !(tt.c2 < cnear_s)) {
+                        tt.i2 = NONE;
+                        tt.c2 = f64_inf();
+                    }
+                    if (tt.i1 != NONE && !(tt.c1 < cnear_s)) tt.init();
                     if (overflow) {  // a radius far beyond the cell size: this wave resolves the sample on its own
                         nnear = 0;
+                        amin = 0.0f;
                         snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);
                     } else if (tt.i1 != NONE) {
                         // the two cheapest, both lines of sight in flight together (rrt.py:519); the second counts only if needed
@@ -1226,7 +1249,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (c.consume != 0u) {  // every wave of the group: its own parked entries above the lower bound
                     double wc;
                     uint32_t wi, nval;
-                    consume_list(Xk, c.bound, c.lbc, c.lbi, own_nlist, wc, wi, nval);
+                    float wam;
+                    consume_list(Xk, c.bound, c.lbc, c.lbi, own_nlist, wc, wi, nval, wam);
                     if (lane == 0) {
                         GSlot sl_;
                         sl_.c1 = wc;
@@ -1235,6 +1259,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         sl_.i2 = NONE;
                         sl_.hits = 0;
                         sl_.nlist = nval;
+                        sl_.nn_d2 = sl_.nn_idx = NONE;
+                        sl_.pad[0] = __float_as_uint(wam);
+                        sl_.pad[1] = 0;
                         gslot[wave] = sl_;
                     }
                 }
@@ -1263,12 +1290,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 __syncthreads();
                 if (lead && c.consume != 0u) {
                     uint32_t nt = 0, tcl = 0;
+                    float am = FINF;
                     if (lane < WPS) {
                         nt = gslot[sl * WPS + lane].hits;
                         tcl = gslot[sl * WPS + lane].i2;
+                        am = __uint_as_float(gslot[sl * WPS + lane].pad[0]);
                     }
                     ntests += wave_sum_u32(nt);
                     tcells += wave_sum_u32(tcl);
+                    amin = grid_nn ? wave_min_f32_nonneg(am) : 0.0f;  // (shares that streamed under the bound parked nothing above it)
                 }
             }
             if (lead && act && lane == 0) {
@@ -1285,7 +1315,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 r.rmask = rmask;
                 r.dupmask = dupmask;
                 r.nnear = nnear;
-                r.pad = 0;
+                r.amin = amin;
                 r.pc = pc;
 #pragma unroll
                 for (int p2 = 0; p2 < NPMAX; ++p2) {
@@ -1345,8 +1375,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (take) {
                     ok = team_wait(t_go, epoch - LAG, t_fail);
                     DBGT(2);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
+                    if (!grid_nn) {  // (the scan of the node array reads it with plain loads)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
+                    }
                 }
                 if (lane == 0) blk.pad0 = ok ? 0 : 1;
 #pragma unroll
@@ -1367,7 +1399,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (pipe_inf && ((u.b.pad1 & ST_FLAG_STOP) != 0 || u.b.i >= n)) break;  // the run is over (or waits for the host)
                 const int jn = unis32(u.b.j);
                 if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
-                    const uint32_t Xn = at32(nodes_g, (uint32_t)(j0 + t));
+                    const uint32_t Xn = ld_u32<COH>(&at32(nodes_g, (uint32_t)(j0 + t)));
                     if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
                     if (cells_on) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -1433,8 +1465,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
             if (wave == 0) {
                 const bool ok = team_wait(t_go, epoch, t_fail);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
+                if (!grid_nn) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and holds the barrier until it has completed
+                }
                 if (lane == 0) blk.pad0 = ok ? 0 : 1;
             }
             __syncthreads();
@@ -1452,7 +1486,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             c_ell = unif64(u.b.c_ell);
             const int jn = unis32(u.b.j);
             if (t < jn - j0) {  // at most SB new nodes: append them to this CU's node cache and cell fill counts
-                const uint32_t Xn = at32(nodes_g, (uint32_t)(j0 + t));
+                const uint32_t Xn = ld_u32<COH>(&at32(nodes_g, (uint32_t)(j0 + t)));
                 if (j0 + t < lds_nodes) nodes_lds[j0 + t] = Xn;
                 if (cells_on) __hip_atomic_fetch_add(&cellcnt[cell_of(Xn)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -1466,7 +1500,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // index: 0x80000000 + 64 set + kk = sample kk of previous block `set` (pipelined teams: oldest first), set = NP: of this block.
         // They compare like the node indices they stand for (above every snapshot index, previous block first, sample order).
         BRec r;
-        r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnear = r.pad = 0;
+        r.d2s = r.vs = r.los_s = r.flags = r.vbest = r.pstat = r.nnear = 0;
+        r.amin = 0.0f;
         r.nnmask = r.rmask = r.dupmask = 0;
 #pragma unroll
         for (int p2 = 0; p2 < NPMAX; ++p2) r.pnn[p2] = r.pr[p2] = r.pdup[p2] = 0;
@@ -1488,7 +1523,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const float f = (float)nc + __builtin_amdgcn_sqrtf((float)d2), cf = (float)cb;
             if (f * (1.0f - 1.0e-6f) - 4.0e-3f >= cf * (1.0f + 1.0e-6f) + 4.0e-3f) return false;
             if (f * (1.0f + 1.0e-6f) + 4.0e-3f < cf * (1.0f - 1.0e-6f) - 4.0e-3f) return true;
-            return nc + sqrt_u32(d2) < cb;
+            return nc + sqrt_u24(d2) < cb;
         };
         auto harmful = [&](int kk) -> bool { return cheaper_through(newcost[kk], dist2(xq_lds[kk], xv), r.cbest); };
         // Sample k on its own, re-resolved against snapshot + inserted nodes of this block (accepted: acc_k) and of the previous
@@ -1499,9 +1534,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const unsigned long long rs0 = __builtin_amdgcn_s_memtime();
             bool rs_redo = false;
 #endif
-#ifdef RRT_STAMPS_LOS
-            unsigned long long rs_los = 0, rs_nlos = 0;
-#endif
             BRecWords rku;  // the same record in every lane: kept in scalar registers
             rku.r = brec[bsel][k];
 #pragma unroll
@@ -1511,10 +1543,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 rku.w[w] = ((u64)hi << 32) | lo;
             }
             const BRec &rk = rku.r;
-#ifdef RRT_STAMPS_RS
-            unsigned long long rst_ = rs0;
-#endif
-            RST(0);  // record to scalar registers
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, k);
             uint32_t vn = rk.vs, d2n = rk.d2s;
             double Vn = rk.Vs;
@@ -1541,7 +1569,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const bool dup = (rk.flags & 1u) != 0 || (rk.dupmask & acc_k) != 0 || pdup_hit;
             const u64 nm = rk.nnmask & acc_k;
             bool nn_inblock = false;
-            RST(1);  // distances, masks
             if (nm | pany) {  // nearest is an inserted block node: smallest distance, lowest node index on ties (oldest block first)
                 nn_inblock = true;
                 uint32_t bestd = NONE, axy = Xk;
@@ -1570,25 +1597,18 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 d2n = bestd;
                 int cc = 0;
-#ifdef RRT_STAMPS_LOS
-                const unsigned long long l0_ = __builtin_amdgcn_s_memtime();
-#endif
                 nocoll = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:424
-#ifdef RRT_STAMPS_LOS
-                if (__builtin_amdgcn_readfirstlane((int)nocoll) >= 0) rs_los += __builtin_amdgcn_s_memtime() - l0_;
-                rs_nlos += 1;
-#endif
                 cells = (uint32_t)cc;
             }
-            RST(2);  // nearest among block nodes + its line of sight
             acc = nocoll && !dup && !(check_full && j0 + __builtin_popcountll(acc_k) == n);  // rrt.py:425
             uint32_t vbest = vn;
-            cbest = Vn + sqrt_u32(d2n);
+            cbest = Vn + sqrt_u24(d2n);
             if (acc && star) {
                 const double cnear = cbest;
                 if (nn_inblock) {
-                    const double cnear_s = rk.Vs + sqrt_u32(rk.d2s);
-                    if (cnear > cnear_s && pi == NONE) {  // entries between the two bounds were never priced: redo the snapshot
+                    // (only when the ball can hold an entry between the two bounds: the owner's lower bound of the cheapest entry at
+                    //  or above its bound says so -- nearly never, and the search of the ball is what makes a round slow)
+                    if (pi == NONE && (double)rk.amin < cnear && cnear > rk.Vs + sqrt_u24(rk.d2s)) {  // entries between the two bounds were never priced: redo the snapshot
                                                           // part (a parent found below the old bound stays the cheapest: same tests)
                         ntests = 0;
                         tcells = 0;
@@ -1601,7 +1621,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         pi = NONE;
                     }
                 }
-                RST(3);  // cbest, redo decision
                 // inserted block nodes within r_rewire, in (cost, index) order, while they beat the snapshot's best
                 u64 rm = rk.rmask & acc_k;
                 u64 rmp[NP], rmany = rm;
@@ -1618,7 +1637,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     double cn = f64_inf();
                     uint32_t ci = NONE;
                     if (rm & lbit) {
-                        const double c = newcost[lane] + sqrt_u32(dk);
+                        const double c = newcost[lane] + sqrt_u24(dk);
                         if (c < cnear) {
                             cn = c;
                             ci = 0x80000000u + (uint32_t)NP * 64u + (uint32_t)lane;
@@ -1627,7 +1646,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #pragma unroll
                     for (int p2 = 0; p2 < NP; ++p2) {
                         if (PIPE && (rmp[p2] & lbit)) {
-                            const double c = prevcost[p2][lane] + sqrt_u32(dkp[p2]);
+                            const double c = prevcost[p2][lane] + sqrt_u24(dkp[p2]);
                             const uint32_t ref = 0x80000000u + (uint32_t)(NP - 1 - p2) * 64u + (uint32_t)lane;
                             if (c < cnear && key_lt(c, ref, cn, ci)) {
                                 cn = c;
@@ -1644,14 +1663,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     for (int p2 = 0; p2 < NP; ++p2)
                         if (set == NP - 1 - p2) axy = (uint32_t)__builtin_amdgcn_readlane((int)xop[p2], (int)kk);
                     int cc = 0;
-#ifdef RRT_STAMPS_LOS
-                    const unsigned long long l0_ = __builtin_amdgcn_s_memtime();
-#endif
                     const bool ok = los_wave(og, H, axy, Xk, lane, cc);  // rrt.py:519
-#ifdef RRT_STAMPS_LOS
-                    if (__builtin_amdgcn_readfirstlane((int)ok) >= 0) rs_los += __builtin_amdgcn_s_memtime() - l0_;
-                    rs_nlos += 1;
-#endif
                     ntests += 1;
                     tcells += (uint32_t)cc;
                     if (ok) {
@@ -1671,7 +1683,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     vbest = pi;
                     cbest = pc;
                 }
-                RST(4);  // candidate loop
             }
             if (lane == 0) {  // the final record of this sample (pad = 1: nnear already counts the block's nodes)
                 BRec &f = brec[bsel][k];
@@ -1681,18 +1692,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 f.vbest = vbest;
                 f.pstat = (ntests << 20) | (tcells & 0xfffffu);
                 f.nnear = nnear;
-                f.pad = 1;
+                f.flags = rk.flags | 2u;
                 newcost[k] = cbest;
             }
-            RST(7);  // final record
 #ifdef RRT_STAMPS
             if (t == 0) {
                 dbg[rs_redo ? 10 : 12] += __builtin_amdgcn_s_memtime() - rs0;
                 dbg[rs_redo ? 11 : 5] += 1;
-#ifdef RRT_STAMPS_LOS
-                dbg[14] += rs_los;   // (instead of wave 1's prefetch time)
-                dbg[15] += rs_nlos;  // (instead of wave 0's wait at the end-of-block barrier)
-#endif
             }
 #endif
         };
@@ -1874,9 +1880,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
             if (lane == 0) pre_state = ok ? 1u : 2u;
 #ifdef RRT_STAMPS
-#ifndef RRT_STAMPS_LOS
             if (lane == 0) dbg[14] += __builtin_amdgcn_s_memtime() - pf0;
-#endif
 #endif
         }
         if (PIPE && wave == 2 && pre_smp) {  // (the samples: a wave of their own, one memory round trip less in a row)
@@ -1921,7 +1925,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                             if (cbest < cmin_soln) {  // np.argmin keeps the first minimum (rrt.py:632)
                                 cmin_soln = cbest;
                                 vbest_soln = jk;
-                                c_ell = cmin_soln + sqrt_u32(dist2(xg, Xk));
+                                c_ell = cmin_soln + sqrt_u24(dist2(xg, Xk));
                                 cut = true;  // the ellipse changed: later samples of this block are stale (rrt.py:698-700)
                             }
                             if (first) cut = true;  // sampling switches from free space to the ellipse (rrt.py:695)
@@ -1971,7 +1975,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         uint32_t nprevnear = 0;
 #pragma unroll
                         for (int p2 = 0; p2 < NP; ++p2) nprevnear += PIPE ? (uint32_t)__builtin_popcountll(f.pr[p2] & A_prev[p2]) : 0u;
-                        statred[lane * 5 + 2] += f.pad ? f.nnear
+                        statred[lane * 5 + 2] += (f.flags & 2u) ? f.nnear
                                                        : f.nnear + (uint32_t)__builtin_popcountll(f.rmask & acc_exact & ltmask) + nprevnear;
                         statred[lane * 5 + 4] += f.pstat >> 20;
                         statred[lane * 5 + 3] += f.pstat & 0xfffffu;
@@ -2034,31 +2038,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
             // state first (write-through), then everything the commit stored, then the flag
             DBGT(9);
-            if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0, true);
+            if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0);
             DBGT(4);
         }
-#ifdef RRT_EXP_FLAGWAVE
-        if (PIPE && wave == 0 && !remote_ok && lane == 0) __hip_atomic_store(&L.pubreq, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (PIPE && wave == 3) {  // the go flag leaves from a wave that has nothing else in flight: wave 0 never waits for it
-            uint32_t v;
-            for (;;) {
-                v = __hip_atomic_load(&L.pubreq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (v != 0u) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (lane == 0) {
-                if (v != 0xffffffffu) __hip_atomic_store(t_go, v, RRT_RLX_AGENT);
-                __hip_atomic_store(&L.pubreq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-#endif
         STAMP(4);
         __syncthreads();
-#ifdef RRT_STAMPS_LOS
-        DBGT(0);  // (slot 15 counts lines of sight in this build)
-#else
         DBGT(15);
-#endif
         {
             const BlkState b = blk;
             if (G > 1 && unis32(b.pad0) != 0) {
