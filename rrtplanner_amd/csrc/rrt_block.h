@@ -295,7 +295,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // steps (of 64 records) of the near-set stream a wave has in flight: two where one wave streams a sample's whole ball, one
     // where a group of waves shares it (a wave of a group rarely has a second step, and the team kernels sit at the register cap:
     // measured, profiles/r02_experiments.md)
-    constexpr int CG = (BSM == 16) ? 2 : 1;
+#ifndef RRT_CG16
+#define RRT_CG16 2
+#endif
+    constexpr int CG = (BSM == 16) ? (ROLE == ROLE_COMMIT ? 2 : RRT_CG16) : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
     auto &nnx = L.nnx;
     auto &brec = L.brec;
@@ -412,6 +415,23 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     } while (0)
 #endif
 
+#if defined(RRT_STAMPS) && defined(RRT_STAMPS_OWNER)
+    unsigned long long wst_ = 0;
+#define WST0() (wst_ = __builtin_amdgcn_s_memtime())
+#define WST(k)                                                     \
+    do {                                                           \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        if (PIPE && g == 1 && t == 0) dbg[k] += now_ - wst_;       \
+        wst_ = now_;                                               \
+    } while (0)
+#else
+#define WST0() \
+    do {       \
+    } while (0)
+#define WST(k) \
+    do {       \
+    } while (0)
+#endif
     const double xc0 = ((double)(D->xs[0] + D->xg[0])) / 2.0, xc1 = ((double)(D->xs[1] + D->xg[1])) / 2.0;
     const double d2sg = (double)dist2(xs, xg);
     const double C00 = D->C[0], C01 = D->C[1], C10 = D->C[2], C11 = D->C[3];
@@ -444,9 +464,27 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     //                  the second cheapest so far.
     //   consume_list   only when both are blocked: the parked list is priced and the entries still open are tested.
     //   count_tests    the statistics as the sequential loop counts them.
+    // Where one wave resolves a sample (BSM == 16) the first 256 entries of its list live in LDS, the rest in HBM: a sample whose
+    // two cheapest candidates are blocked reads its list back several times, and that sample is the one its whole block waits
+    // for.  Groups of waves (each with a share of the ball) keep their lists in HBM.
+    constexpr bool LDSLIST = BSM == 16;
     const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE * (G + (PIPE ? 1 : 0))));  // the engine sizes the spill area per team member
-    u32x4 *const clist_base = reinterpret_cast<u32x4 *>(spill) + (size_t)(g * NWAVE) * (size_t)clist_cap;  // this member's 16 lists
+    u32x4 *const clist_base = reinterpret_cast<u32x4 *>(spill) + (size_t)(g * NWAVE) * (size_t)clist_cap;  // this member's 16 lists (and go2goal's scratch)
     u32x4 *const clist = clist_base + (size_t)wave * (size_t)clist_cap;
+    RRT_LDS u32x4 *const clist_l =
+        (RRT_LDS u32x4 *)(smem + (size_t)lds_chunks * CHUNK * sizeof(uint32_t) + (size_t)MAX_CELLS * sizeof(uint32_t)) + (size_t)wave * BLOCK_LIST_CAP;
+    auto lget = [&](uint32_t p) -> u32x4 {
+        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) return clist_l[p];
+        return clist[p];
+    };
+    auto lput = [&](uint32_t p, u32x4 e) {
+        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) clist_l[p] = e;
+        else clist[p] = e;
+    };
+    auto lput_y = [&](uint32_t p, uint32_t y) {
+        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) clist_l[p].y = y;
+        else clist[p].y = y;
+    };
     // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
     auto screen_of = [](double c) -> float { return (float)c * (1.0f + 1.0e-6f) + 4.0e-3f; };
     auto hi_of = [](double c) -> uint32_t { return (uint32_t)((unsigned long long)__double_as_longlong(c) >> 32); };
@@ -486,7 +524,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (pm == 0) return;
             if (park) {
                 const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                if (pos < clist_cap) clist[pos] = u32x4{rc.y, d2, rc.z, rc.w};
+                if (pos < clist_cap) lput(pos, u32x4{rc.y, d2, rc.z, rc.w});
             }
             nlist += (uint32_t)__builtin_popcountll(pm);
             // screens, cheapest first; none rejects an entry that belongs to the two cheapest
@@ -586,7 +624,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         for (uint32_t p0 = 0; p0 < nlist; p0 += 64) {
             const uint32_t p = p0 + (uint32_t)lane;
             u32x4 e = {NONE, 0u, 0u, 0u};
-            if (p < nlist) e = clist[p];  // {index, d2, vcost}
+            if (p < nlist) e = lget(p);  // {index, d2, vcost}
             const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
             double cn = f64_inf();
             if (p < nlist) {
@@ -603,7 +641,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const unsigned long long om = __ballot(open);
             if (open) {  // positions at or below the ones this iteration has read
                 const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
-                clist[nval + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)};
+                lput(nval + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull)), u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)});
             }
             nval += (uint32_t)__builtin_popcountll(om);
         }
@@ -617,7 +655,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const uint32_t p = p0 + (uint32_t)lane;
             const bool have = p < nval;
             u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
-            if (have) e = clist[p];
+            if (have) e = lget(p);
             const uint32_t axy = have ? node_xy(e.x) : X;
             const rrt_line_t ln = rrt_line_setup(ux(axy), uy(axy), ux(X), uy(X));
             const int L = ln.major;
@@ -640,7 +678,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         cells = k0 + u + 1;
                     }
             }
-            if (have) clist[p].y = (uint32_t)cells;  // cells read by this test, for count_tests
+            if (have) lput_y(p, (uint32_t)cells);  // cells read by this test, for count_tests
             double cn = f64_inf();
             uint32_t ci = NONE;
             if (have && !blocked) {
@@ -656,10 +694,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     };
 
     // The tests the sequential loop makes over a consumed list: up to and including the first passing entry (wc, wi), or all.
-    auto count_tests = [&](const u32x4 *list, uint32_t nval, double wc, uint32_t wi, uint32_t &ntests, uint32_t &tcells) {
+    auto count_tests = [&](uint32_t nval, double wc, uint32_t wi, uint32_t &ntests, uint32_t &tcells) {
         uint32_t nt = 0, tcl = 0;
         for (uint32_t p = (uint32_t)lane; p < nval; p += 64) {
-            const u32x4 e = list[p];
+            const u32x4 e = lget(p);
             const double cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
             if (wi == NONE || !key_lt(wc, wi, cn, e.x)) {
                 nt += 1;
@@ -708,7 +746,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             uint32_t nval = 0;
             float am_;
             consume_list(X, bound, lbc, lbi, nlist, pc, pi, nval, am_);
-            count_tests(clist, nval, pc, pi, ntests, tcells);
+            count_tests(nval, pc, pi, ntests, tcells);
             return;
         }
     };
@@ -753,6 +791,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             return;
         }
         amin = 0.0f;  // both are below the bound: unknown unless the parked list tells
+#ifdef RRT_EXP_NOCONSUME
+        return;  // timing experiment only (wrong trees): what the blocked-candidate path of single-wave owners costs
+#endif
         if (nlist > clist_cap) {  // the list overflowed: stream again, bounded, above the two that are blocked
             uint32_t nn2 = 0;
             snapshot_parent(X, j0, false, bound, pc, pi, nn2, ntests, tcells, tt.c2, tt.i2 + 1);
@@ -760,7 +801,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         }
         uint32_t nval = 0;
         consume_list(X, bound, tt.c2, tt.i2 + 1, nlist, pc, pi, nval, amin);
-        count_tests(clist, nval, pc, pi, ntests, tcells);
+        count_tests(nval, pc, pi, ntests, tcells);
     };
     // near()[0] (rrt.py:150-155) of one sample over the snapshot [0, j0) by ONE wave: 256 nodes per step, 4 per lane
     auto wave_scan_nearest = [&](uint32_t X, int j0, uint32_t &d2s, uint32_t &vs) {
@@ -999,9 +1040,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             Top2 tt0;
             tt0.init();
             uint32_t nlist0 = 0, nnear0 = 0;
+            WST0();
             if (grid_nn) {  // the record stream first: it names the nearest node unless the ball is empty
                 uint32_t nd2, nidx;
                 stream_cells(Xk, j0, false, f64_inf(), -1.0, 0u, 0, 1, tt0, nnear0, nlist0, nd2, nidx);
+                WST(4);
                 if (nnear0 != 0) {
                     d2s = nd2;
                     vs = nidx;
@@ -1043,6 +1086,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             double pc = f64_inf();
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
             const double cnear_s = Vs + sqrt_u24(d2s);
+            WST(5);
 #ifdef RRT_STAMPS
             const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1057,8 +1101,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #ifdef RRT_STAMPS
             wcyc_los += __builtin_amdgcn_s_memtime() - tl0;
 #endif
+            WST(6);
             int cells = 0;
             const bool free_s = los_finish(lp, og, H, vsxy, Xk, lane, cells);
+            WST(7);
             if (lane == 0) {
                 BRec r;
                 r.d2s = d2s;
@@ -1277,7 +1323,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     }
                     wave_min_f64_idx(gc, gi);
                     uint32_t nt = 0, tcl = 0;
-                    count_tests(clist, gslot[wave].nlist, gc, gi, nt, tcl);
+                    count_tests(gslot[wave].nlist, gc, gi, nt, tcl);
                     if (lane == 0) {
                         gslot[wave].hits = nt;
                         gslot[wave].i2 = tcl;
@@ -1330,7 +1376,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         wcyc_acc += __builtin_amdgcn_s_memtime() - tb0;
 #endif
         STAMP(2);
+        WST0();
         __syncthreads();
+        WST(8);
         STAMP(3);
         }  // worker
 

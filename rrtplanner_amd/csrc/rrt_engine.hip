@@ -50,8 +50,8 @@ struct rrt_batch {
     int32_t gridW = 0, gridH = 0;
     uint32_t flags = 0;
     bool use_block = false;     // block-parallel kernel (rrt_block.h) instead of the one-sample-per-iteration kernel
-    int32_t blk_lds_chunks = 1; // node chunks cached in LDS by the block kernel
-    size_t blk_lds_bytes = 0;
+    int32_t blk_lds_chunks = 1; // node chunks cached in LDS by the block kernel: teams of 8 and more workers ...
+    int32_t blk_lds_chunks16 = 1; // ... and the kernels that also keep their parked-entry lists there
     int32_t team = 1;           // workgroups (CUs) per query of the block kernel that scan and resolve (rrt_block.h, teams)
     bool pipe_team = false;     // the team is pipelined: one more workgroup per query, which only commits
     bool pipe = false;          // the last launch ran the pipelined team kernel
@@ -419,13 +419,15 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         }
     }
     b->spill_stride = chunks * CHUNK * (b->team + 1);  // per member (and a pipelined team's committer): 256 parked entries per wave and node chunk; also go2goal's cost array
-    {   // block kernel LDS: [node cache | cell fill counts 16 KiB]
+    {   // block kernel LDS: [node cache | cell fill counts 16 KiB | the waves' parked-entry lists 64 KiB (teams of up to 4 workers and
+        // single CUs, where one wave resolves a sample: rrt_block.h LDSLIST)]
         const size_t budget = (size_t)ctx->max_lds - block_kernel_static_lds(b->team);
         const size_t fixed = (size_t)MAX_CELLS * sizeof(uint32_t);
         if (b->use_block) {
             int nc = (int)((budget - fixed) / ((size_t)CHUNK * sizeof(uint32_t)));
             b->blk_lds_chunks = nc > chunks ? chunks : nc;
-            b->blk_lds_bytes = fixed + (size_t)b->blk_lds_chunks * CHUNK * sizeof(uint32_t);
+            int nc16 = (int)((budget - fixed - BLOCK_LIST_LDS_BYTES) / ((size_t)CHUNK * sizeof(uint32_t)));
+            b->blk_lds_chunks16 = nc16 > chunks ? chunks : nc16;
             b->rec_stride = cell_records_needed(ctx->W, ctx->H, n_cap);
         }
     }
@@ -705,11 +707,13 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     BatchView v = make_view(b);
     dim3 ig((unsigned)((b->bitmap_words + 255) / 256 > 64 ? 64 : (b->bitmap_words + 255) / 256), (unsigned)b->Q);
     if (b->use_block) {
-        v.lds_chunks = b->blk_lds_chunks;
         // after a hand-off timed out this one launch continues the batch with one CU per query; the team size the batch was
         // created with stays and the next launch uses it again
         const int team = b->one_cu_once ? 1 : b->team;
         b->one_cu_once = false;
+        const bool lists = team <= 4;  // one wave per sample: its parked entries stay in LDS
+        v.lds_chunks = lists ? b->blk_lds_chunks16 : b->blk_lds_chunks;
+        const size_t blk_lds_bytes = (size_t)MAX_CELLS * sizeof(uint32_t) + (lists ? BLOCK_LIST_LDS_BYTES : 0) + (size_t)v.lds_chunks * CHUNK * sizeof(uint32_t);
         // a two-deep pipeline of super-blocks (one more workgroup per team, which only commits) for teams of 8 and more
         bool pipe = team > 1 && b->pipe_team;
 #ifdef RRT_STAMPS
@@ -719,12 +723,12 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         bool inf = false;  // any Informed query in this launch?
         for (const auto &d : b->h_desc)
             if (d.status == ST_RUNNING && d.alg == 2) inf = true;
-        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(team, pipe, inf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->blk_lds_bytes));
+        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(team, pipe, inf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         if (team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
         const dim3 tg(team > 1 ? (unsigned)(b->team_qpad * (team + (pipe ? 1 : 0))) : (unsigned)b->Q);
-        hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf), tg, dim3(TPB), b->blk_lds_bytes, ctx->stream, v);
+        hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf), tg, dim3(TPB), blk_lds_bytes, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;

@@ -81,6 +81,8 @@ struct BatchView {
     const uint8_t *sample_heading;  // [Q][n_cap]       heading index of sample i
 };
 
+constexpr int BLOCK_LIST_CAP = 256;                                  // block kernel, one wave per sample: parked entries per wave kept in LDS
+constexpr size_t BLOCK_LIST_LDS_BYTES = (size_t)NWAVE * BLOCK_LIST_CAP * 16;  // 64 KiB
 constexpr int MAX_CELLS = 4096;  // cells per query (their fill counts live in LDS: 16 KiB)
 
 // Near set of one wave: every wave keeps the within-radius nodes of its own stripe in its own LDS
