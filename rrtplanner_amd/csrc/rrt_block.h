@@ -651,18 +651,27 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // loads in flight); the answer is the cheapest passing entry.  (Ranking up to 16 open entries and testing them in
         // (cost, index) order, one wave per line of sight and 8 in flight, was measured slower on every bench workload:
         // profiles/r02_experiments.md.)
-        for (uint32_t p0 = 0; p0 < nval; p0 += 64) {
-            const uint32_t p = p0 + (uint32_t)lane;
+        // A short list spreads every segment over 2 or 4 lanes (16-cell pieces dealt round-robin), so that up to 16 / 32 open
+        // entries are through after one / two memory round trips instead of four.
+        for (uint32_t p0 = 0; p0 < nval;) {
+            const uint32_t rem = nval - p0;
+            // log2 of the lanes per entry (single CUs only: on teams the same split measured slower, profiles/r02_experiments.md)
+            const int sh = G > 1 ? 0 : (rem <= 16 ? 2 : (rem <= 32 ? 1 : 0));
+            const int S = 1 << sh, part = lane & (S - 1);
+            const uint32_t p = p0 + ((uint32_t)lane >> sh);
             const bool have = p < nval;
             u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
             if (have) e = lget(p);
             const uint32_t axy = have ? node_xy(e.x) : X;
             const rrt_line_t ln = rrt_line_setup(ux(axy), uy(axy), ux(X), uy(X));
             const int L = ln.major;
-            bool blocked = false;
-            int cells = L + 1;
-            constexpr int WU = 16;
-            for (int k0 = 0; __any(!blocked && k0 <= L); k0 += WU) {
+            constexpr int WU = 16, NOHIT = 0x7fffffff;
+            int fb = NOHIT;  // first blocked cell among this lane's pieces
+            for (int it = 0;; ++it) {
+                const unsigned long long hitm = __ballot(fb != NOHIT);
+                const bool grp_hit = ((hitm >> (lane & ~(S - 1))) & ((1ull << S) - 1ull)) != 0;
+                if (!__any(!grp_hit && it * S * WU <= L)) break;  // (after a full round every cell below (it S WU) has been read)
+                const int k0 = (it * S + part) * WU;
                 uint8_t v[WU];
 #pragma unroll
                 for (int u = 0; u < WU; ++u) {  // unconditional loads (clamped to the segment's last cell)
@@ -673,18 +682,26 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
 #pragma unroll
                 for (int u = 0; u < WU; ++u)
-                    if (!blocked && k0 + u <= L && v[u] != 0) {
-                        blocked = true;
-                        cells = k0 + u + 1;
-                    }
+                    if (fb == NOHIT && k0 + u <= L && v[u] != 0) fb = k0 + u;
             }
-            if (have) lput_y(p, (uint32_t)cells);  // cells read by this test, for count_tests
+            if (sh >= 1) {
+                const int o = __builtin_amdgcn_update_dpp(NOHIT, fb, 0xB1, 0xf, 0xf, false);  // lane ^ 1
+                fb = o < fb ? o : fb;
+            }
+            if (sh >= 2) {
+                const int o = __builtin_amdgcn_update_dpp(NOHIT, fb, 0x4E, 0xf, 0xf, false);  // lane ^ 2
+                fb = o < fb ? o : fb;
+            }
+            const bool blocked = fb != NOHIT;
+            const int cells = blocked ? fb + 1 : L + 1;
+            if (have && part == 0) lput_y(p, (uint32_t)cells);  // cells read by this test, for count_tests
             double cn = f64_inf();
             uint32_t ci = NONE;
-            if (have && !blocked) {
+            if (have && part == 0 && !blocked) {
                 cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
                 ci = e.x;
             }
+            p0 += 64u >> sh;
             wave_min_f64_idx(cn, ci);
             if (ci != NONE && key_lt(cn, ci, wc, wi)) {
                 wc = cn;
