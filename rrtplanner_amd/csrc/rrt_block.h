@@ -267,6 +267,8 @@ struct BlockLds {
     alignas(16) ParRound par;
     uint32_t xqp_lds[PIPE ? NP : 1][PIPE ? 64 : 1];  // pipelined teams: the samples of the previous super-block(s) ...
     double prevcost[PIPE ? NP : 1][PIPE ? 64 : 1];   // ... and (committer) the exact costs of the nodes they inserted
+    uint32_t help_n[NWAVE], help_x[NWAVE];  // single-wave owners: open candidates of a blocked sample that all waves test together, its coordinates
+    uint32_t help_any;
     alignas(16) GSlot gslot[NWAVE];
     alignas(16) GCtl gctl[BSM];
 #ifdef RRT_STAMPS
@@ -445,6 +447,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         for (int k = t; k < lds_nodes; k += TPB) nodes_lds[k] = (k < j) ? nodes_g[k] : n0;
         for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
         if (t < SB * 5) statred[t] = 0;
+        if (t < NWAVE) L.help_n[t] = 0;
+        if (t == 0) L.help_any = 0;
     }
     __syncthreads();
 
@@ -484,6 +488,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     auto lput_y = [&](uint32_t p, uint32_t y) {
         if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) clist_l[p].y = y;
         else clist[p].y = y;
+    };
+    // the list of another wave of this workgroup (the cooperative test of a blocked sample's candidates)
+    auto lget_w = [&](int w, uint32_t p) -> u32x4 {
+        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) return (clist_l + ((ptrdiff_t)(w - wave)) * BLOCK_LIST_CAP)[p];
+        return (clist_base + (size_t)w * (size_t)clist_cap)[p];
+    };
+    auto lput_y_w = [&](int w, uint32_t p, uint32_t y) {
+        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) (clist_l + ((ptrdiff_t)(w - wave)) * BLOCK_LIST_CAP)[p].y = y;
+        else (clist_base + (size_t)w * (size_t)clist_cap)[p].y = y;
     };
     // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
     auto screen_of = [](double c) -> float { return (float)c * (1.0f + 1.0e-6f) + 4.0e-3f; };
@@ -614,12 +627,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // every open entry is tested, one line of sight per LANE.
     // (wc, wi) = the cheapest passing entry; every entry with a key up to it has been tested and holds its cell count.
     // amin: a single-precision lower bound of the cheapest parked entry that is NOT below the bound (+inf: none).
-    auto consume_list = [&](uint32_t X, double bound, double lbc, uint32_t lbi, uint32_t nlist, double &wc, uint32_t &wi, uint32_t &nval,
-                            float &amin) {
+    auto consume_price = [&](double bound, double lbc, uint32_t lbi, uint32_t nlist, uint32_t &nval, float &amin) {
         const float boundf = screen_of(bound);
         nval = 0;
-        wc = f64_inf();
-        wi = NONE;
         float am = FINF;
         for (uint32_t p0 = 0; p0 < nlist; p0 += 64) {
             const uint32_t p = p0 + (uint32_t)lane;
@@ -646,6 +656,17 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             nval += (uint32_t)__builtin_popcountll(om);
         }
         amin = wave_min_f32_nonneg(am);
+#if defined(RRT_STAMPS) && defined(RRT_STAMPS_OWNER)
+        if (PIPE && g == 1 && t == 0) {
+            L.dbg[9] += nval;
+            L.dbg[10] += 1;
+            L.dbg[11] += nlist;
+        }
+#endif
+    };
+    auto consume_walk = [&](uint32_t X, uint32_t nval, double &wc, uint32_t &wi) {
+        wc = f64_inf();
+        wi = NONE;
         if (nval == 0) return;  // every entry was tried
         // one line of sight PER LANE, 64 entries at a time, every open entry tested (each lane walks its own segment, 16 cell
         // loads in flight); the answer is the cheapest passing entry.  (Ranking up to 16 open entries and testing them in
@@ -708,6 +729,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 wi = ci;
             }
         }
+    };
+
+    auto consume_list = [&](uint32_t X, double bound, double lbc, uint32_t lbi, uint32_t nlist, double &wc, uint32_t &wi, uint32_t &nval,
+                            float &amin) {
+        consume_price(bound, lbc, lbi, nlist, nval, amin);
+        consume_walk(X, nval, wc, wi);
     };
 
     // The tests the sequential loop makes over a consumed list: up to and including the first passing entry (wc, wi), or all.
@@ -781,10 +808,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // of a block in flight turns out to be the sample's nearest: the bound moves up, and only an entry between the old bound and
     // the new one makes it search the ball again.
     auto lower_f32 = [](double c) -> float { return __builtin_fmaxf((float)c * (1.0f - 1.0e-6f) - 4.0e-3f, 0.0f); };
+    // defer: the blocked-candidate list is only priced here (open = its open entries, left in the list); the caller has them tested
     auto finish_parent = [&](uint32_t X, int j0, double bound, Top2 tt, uint32_t nlist, double &pc, uint32_t &pi, uint32_t &ntests, uint32_t &tcells,
-                             float &amin) {
+                             float &amin, bool defer, uint32_t &open) {
         pc = f64_inf();
         pi = NONE;
+        open = 0;
         amin = tt.i1 == NONE ? FINF : lower_f32(tt.c1);
         if (tt.i1 == NONE || !(tt.c1 < bound)) return;  // rrt.py:518, strict
         amin = tt.i2 == NONE ? FINF : lower_f32(tt.c2);  // (the cheapest entry is below the bound)
@@ -817,6 +846,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             return;
         }
         uint32_t nval = 0;
+        if (defer) {
+            consume_price(bound, tt.c2, tt.i2 + 1, nlist, nval, amin);
+            open = nval;
+            return;
+        }
         consume_list(X, bound, tt.c2, tt.i2 + 1, nlist, pc, pi, nval, amin);
         count_tests(nval, pc, pi, ntests, tcells);
     };
@@ -1041,6 +1075,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #ifdef RRT_STAMPS
         const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
+        uint32_t my_open = 0, my_ntests = 0, my_tcells = 0;  // single-wave owner of a blocked sample: see below
         if constexpr (WPS == 1) {
         const int sidx = wg * BSM + wave;  // the sample this wave owns (waves BSM.. of a small-BSM team member idle here)
 #ifdef RRT_EXP_PRIO
@@ -1050,6 +1085,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
         else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
+        // A sample whose two cheapest candidates are blocked leaves its open candidates in its list; behind the barrier ALL waves
+        // of the workgroup test them, four lines of sight per wave and memory round trip (one wave on its own walks them lane by
+        // lane, four round trips, while the other fifteen wait for it: it was a third of a single-wave owner's block).
+        const bool coop = grid_nn && rad < 64;  // (every candidate segment shorter than 64 cells)
         if (wave < BSM && sidx < nb) {
             const int k = wave;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, sidx);  // every wave holds the same xv
@@ -1111,7 +1150,14 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (grid_nn) {
                 nnear = star ? nnear0 : 0u;
                 amin = FINF;  // (an empty ball)
-                if (star && nnear0 != 0) finish_parent(Xk, j0, cnear_s, tt0, nlist0, pc, pi, ntests, tcells, amin);
+                if (star && nnear0 != 0) finish_parent(Xk, j0, cnear_s, tt0, nlist0, pc, pi, ntests, tcells, amin, coop, my_open);
+                my_ntests = ntests;
+                my_tcells = tcells;
+                if (my_open != 0 && lane == 0) {
+                    L.help_n[wave] = my_open;
+                    L.help_x[wave] = Xk;
+                    L.help_any = 1u;
+                }
             } else if (star) {
                 snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);  // no block node is in the cells yet
             }
@@ -1396,6 +1442,68 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         WST0();
         __syncthreads();
         WST(8);
+        if constexpr (WPS == 1) {
+            if (uni32(L.help_any) != 0u) {
+                for (int w = 0; w < NWAVE; ++w) {
+                    const uint32_t n = uni32(L.help_n[w]);
+                    if (n == 0) continue;
+                    const uint32_t Xw = uni32(L.help_x[w]);
+                    for (uint32_t c = (uint32_t)((wave - w) & (NWAVE - 1)); c * 4u < n; c += NWAVE) {  // this wave's groups of four candidates
+                        const uint32_t pq = c * 4u + (uint32_t)(lane & 3);
+                        uint32_t axy = Xw;
+                        if (pq < n) axy = node_xy(lget_w(w, pq).x);
+                        uint32_t a4[4];
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) a4[q4] = (uint32_t)__builtin_amdgcn_readlane((int)axy, q4);
+                        const int nc = (int)(n - c * 4u < 4u ? n - c * 4u : 4u);
+                        bool ok4[4];
+                        int cells4[4];
+                        los_batch_n<4>(og, H, a4, nc, Xw, lane, ok4, cells4);
+                        uint32_t res = 0;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            if (lane == q4) res = (uint32_t)cells4[q4] | (ok4[q4] ? 0u : 0x80000000u);
+                        if (lane < nc) lput_y_w(w, c * 4u + (uint32_t)lane, res);  // cells read; bit 31: blocked
+                    }
+                }
+                __syncthreads();
+                if (my_open != 0) {  // the owner: the cheapest passing candidate, the tests the sequential loop makes, the record
+                    double wc = f64_inf();
+                    uint32_t wi = NONE;
+                    for (uint32_t p0 = 0; p0 < my_open; p0 += 64) {
+                        const uint32_t pq = p0 + (uint32_t)lane;
+                        double cn = f64_inf();
+                        uint32_t ci = NONE;
+                        if (pq < my_open) {
+                            const u32x4 e = lget(pq);
+                            lput_y(pq, e.y & 0x7fffffffu);
+                            if ((e.y >> 31) == 0u) {
+                                cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                                ci = e.x;
+                            }
+                        }
+                        wave_min_f64_idx(cn, ci);
+                        if (ci != NONE && key_lt(cn, ci, wc, wi)) {
+                            wc = cn;
+                            wi = ci;
+                        }
+                    }
+                    count_tests(my_open, wc, wi, my_ntests, my_tcells);
+                    if (lane == 0) {
+                        BRec &r = brec[0][wg * BSM + wave];
+                        if (wi != NONE) {
+                            r.cbest = wc;
+                            r.vbest = wi;
+                            r.pc = wc;
+                        }
+                        r.pstat = (my_ntests << 20) | (my_tcells & 0xfffffu);
+                        L.help_n[wave] = 0;
+                    }
+                }
+                if (t == 0) L.help_any = 0;
+                __syncthreads();
+            }
+        }
         STAMP(3);
         }  // worker
 

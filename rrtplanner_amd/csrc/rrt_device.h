@@ -223,4 +223,28 @@ __device__ __forceinline__ void los_batch(const uint8_t *__restrict__ og, int H,
     }
 }
 
+// The same for N lines of sight (N <= LOSB) with fewer registers held.
+template <int N>
+__device__ __forceinline__ void los_batch_n(const uint8_t *__restrict__ og, int H, const uint32_t (&a)[N], int nc, uint32_t b, int lane,
+                                            bool (&ok)[N], int (&cells)[N]) {
+    rrt_line_t ln[N];
+    uint8_t v[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        ln[c] = rrt_line_setup(ux(a[c]), uy(a[c]), ux(b), uy(b));
+        v[c] = 0;
+        if (c < nc && lane <= ln[c].major) {
+            int x, y;
+            rrt_line_cell(&ln[c], lane, &x, &y);
+            v[c] = og[(uint32_t)(x * H + y)];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        const unsigned long long mb = __ballot(v[c] != 0);
+        ok[c] = mb == 0;
+        cells[c] = mb ? (int)__builtin_ctzll(mb) + 1 : ln[c].major + 1;
+    }
+}
+
 }  // namespace rrtdev
