@@ -9,6 +9,7 @@ HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in 
 import csv
 import glob
 import json
+import os
 import sys
 
 KERNEL = "rrt_expand_block_kernel"
@@ -18,7 +19,8 @@ NOTE = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (eac
 
 def mean_counter(dirname, counter):
     vals = []
-    for path in glob.glob(dirname + "/**/*counter_collection.csv", recursive=True):
+    paths = sorted(glob.glob(dirname + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for path in paths[-1:]:  # the latest pass only (gpurun merges every call's output into the same directory)
         for row in csv.DictReader(open(path)):
             if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 vals.append(float(row["Counter_Value"]))
