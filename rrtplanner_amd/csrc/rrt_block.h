@@ -668,6 +668,44 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         wc = f64_inf();
         wi = NONE;
         if (nval == 0) return;  // every entry was tried
+#ifndef RRT_WALKB
+#define RRT_WALKB 8
+#endif
+        if (nval <= (uint32_t)RRT_WALKB && rad < 64) {
+            // a handful (a wave's share of a group's ball, a committer's second search): four segments per memory round trip,
+            // 64 cells of each at once, instead of lane-by-lane walks of up to four round trips
+            for (uint32_t b0 = 0; b0 < nval; b0 += 4) {
+                const uint32_t pq = b0 + (uint32_t)(lane & 3);
+                u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
+                if (pq < nval) e = lget(pq);
+                const uint32_t axy = pq < nval ? node_xy(e.x) : X;
+                uint32_t a4[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) a4[q4] = (uint32_t)__builtin_amdgcn_readlane((int)axy, q4);
+                bool ok4[4];
+                int cells4[4];
+                los_batch_n<4>(og, H, a4, (int)(nval - b0 < 4u ? nval - b0 : 4u), X, lane, ok4, cells4);
+                uint32_t res = 0;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    if (lane == q4) res = (uint32_t)cells4[q4] | (ok4[q4] ? 0u : 0x80000000u);
+                double cn = f64_inf();
+                uint32_t ci = NONE;
+                if (lane < 4 && pq < nval) {
+                    lput_y(pq, res & 0x7fffffffu);
+                    if ((res >> 31) == 0u) {
+                        cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                        ci = e.x;
+                    }
+                }
+                wave_min_f64_idx(cn, ci);
+                if (ci != NONE && key_lt(cn, ci, wc, wi)) {
+                    wc = cn;
+                    wi = ci;
+                }
+            }
+            return;
+        }
         // one line of sight PER LANE, 64 entries at a time, every open entry tested (each lane walks its own segment, 16 cell
         // loads in flight); the answer is the cheapest passing entry.  (Ranking up to 16 open entries and testing them in
         // (cost, index) order, one wave per line of sight and 8 in flight, was measured slower on every bench workload:
