@@ -490,12 +490,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         else clist[p].y = y;
     };
     // the list of another wave of this workgroup (the cooperative test of a blocked sample's candidates)
+    RRT_LDS u32x4 *const clist_l0 = clist_l - (size_t)wave * BLOCK_LIST_CAP;  // wave 0's
     auto lget_w = [&](int w, uint32_t p) -> u32x4 {
-        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) return (clist_l + ((ptrdiff_t)(w - wave)) * BLOCK_LIST_CAP)[p];
+        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) return clist_l0[(size_t)w * BLOCK_LIST_CAP + p];
         return (clist_base + (size_t)w * (size_t)clist_cap)[p];
     };
     auto lput_y_w = [&](int w, uint32_t p, uint32_t y) {
-        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) (clist_l + ((ptrdiff_t)(w - wave)) * BLOCK_LIST_CAP)[p].y = y;
+        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) clist_l0[(size_t)w * BLOCK_LIST_CAP + p].y = y;
         else (clist_base + (size_t)w * (size_t)clist_cap)[p].y = y;
     };
     // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
