@@ -291,7 +291,9 @@ def main():
             out["dtype"] = "int16x2 coordinates / u8 headings / f64 Dubins arc lengths and costs"
             out["roofline"]["kernel"] = "rrt_expand_kernel<false, true>"
             out["config"]["reference_parity"] = "none: the reference only advertises Dubins planners (README.md:12,18-19)"
-            ndub = sum(r.c.sum_near for r in results) + 2 * iters_local + sum(r.c.n_los_cand for r in results)  # priced entries, nearest (length + sweep), candidate sweeps
+            # word evaluations the kernel makes: one per priced near-set entry and one for the nearest node of every iteration (a
+            # tested candidate reuses the word of its pricing; the arc sweeps' own f64 work is not counted)
+            ndub = sum(r.c.sum_near for r in results) + iters_local
             fl = ndub * DUBINS_F64_OPS / (kern_avg_ms * 1e-3) / 1e12
             out["roofline"]["inner"] = {"bound": "valu-f64", "achieved": fl, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / F64_VALU_PEAK_TFLOPS,
                                         "dubins_word_evaluations_per_launch": int(ndub), "f64_ops_per_evaluation": DUBINS_F64_OPS}

@@ -70,6 +70,7 @@ struct rrt_batch {
     int32_t *d_vsoln = nullptr;     //                  [Q][node_stride]
     uint8_t *d_heading = nullptr;   // RRT_FLAG_DUBINS: [Q][node_stride] node headings
     uint8_t *d_shead = nullptr;     //                  [Q][n_cap] sample headings
+    double *d_dubpath = nullptr;    //                  [Q][NWAVE * WCAP][5] the words of the current iteration's near-set entries
     std::vector<uint8_t> stage8;
     uint4 *d_cellrec = nullptr;    // block kernel: near-set records, [Q][rec_stride]
     uint32_t *d_cellcnt = nullptr; // [Q][MAX_CELLS]
@@ -350,7 +351,8 @@ extern "C" int rrt_batch_destroy(rrt_batch *b) {
     (void)hipStreamSynchronize(b->ctx->stream);
     void *ptrs[] = {b->d_desc,  b->d_samples,   b->d_slab,        b->d_bitmap, b->d_unitball,  b->d_cellrec,
                     b->d_spill, b->d_cbest_log, b->d_nearest_log, b->d_j_log,  b->d_accept_log, b->d_cellcnt,
-                    b->d_team,  b->d_kids,      b->d_frontier,    b->d_vsoln,  b->d_heading,   b->d_shead};
+                    b->d_team,  b->d_kids,      b->d_frontier,    b->d_vsoln,  b->d_heading,   b->d_shead,
+                    b->d_dubpath};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -467,6 +469,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     if (flags & RRT_FLAG_DUBINS) {
         ALLOC(b->d_heading, q * b->node_stride);
         ALLOC(b->d_shead, q * n_cap);
+        ALLOC(b->d_dubpath, q * (size_t)(NWAVE * WCAP) * 5 * sizeof(double));
     }
     if (flags & RRT_FLAG_LOGS) {
         ALLOC(b->d_nearest_log, q * n_cap * sizeof(int32_t));
@@ -642,6 +645,7 @@ static BatchView make_view(rrt_batch *b) {
     }
     v.heading = b->d_heading;
     v.sample_heading = b->d_shead;
+    v.dub_path = b->d_dubpath;
     return v;
 }
 

@@ -79,6 +79,7 @@ struct BatchView {
     // Dubins planners (RRT_FLAG_DUBINS; serial kernel only), null otherwise
     uint8_t *heading;               // [Q][node_stride] heading index of every node
     const uint8_t *sample_heading;  // [Q][n_cap]       heading index of sample i
+    double *dub_path;               // [Q][NWAVE * WCAP][5] {t, p, q, len, word} of every priced near-set entry of the current iteration
 };
 
 constexpr int BLOCK_LIST_CAP = 256;                                  // block kernel, one wave per sample: parked entries per wave kept in LDS
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
     uint8_t *heading = DUB ? bv.heading + (size_t)q * bv.node_stride : nullptr;
     const uint8_t *shead = DUB ? bv.sample_heading + (size_t)q * bv.n_cap : nullptr;
     const DubCfg dc{DUB ? D->rho : 1.0, DUB ? D->nh : 1, bv.W, bv.H};
+    double *const dpath = DUB ? bv.dub_path + (size_t)q * (size_t)(NWAVE * WCAP) * 5 : nullptr;
     const uint32_t *samples = bv.samples + (size_t)q * bv.n_cap;
     uint32_t *nodes_g = bv.nodes + (size_t)q * bv.node_stride;
     const u32x4 *nodes_g4 = reinterpret_cast<const u32x4 *>(nodes_g);
@@ -589,7 +591,14 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                     if (g < T) {
                         const u32x2 e = ((RRT_LDS u32x2 *)wlist_lds)[lo * WCAP + (g - base)];  // {node, d2}
                         pk_idx[g] = e.x;
-                        pk_cost[g] = node_cost(e.x) + dub_between_dev(node_xy(e.x), node_h(e.x), xq, hq, dc).len;
+                        const dub_path_t pth = dub_between_dev(node_xy(e.x), node_h(e.x), xq, hq, dc);
+                        pk_cost[g] = node_cost(e.x) + pth.len;
+                        double *dp = dpath + (size_t)g * 5;  // kept for the test rounds: a word is evaluated once
+                        dp[0] = pth.t;
+                        dp[1] = pth.p;
+                        dp[2] = pth.q;
+                        dp[3] = pth.len;
+                        dp[4] = (double)pth.word;
                     }
                 }
                 if (wave == NWAVE - 1) {  // the nearest node: its word, the cost through it, its sweep (rrt.py:422-424)
@@ -659,8 +668,24 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                             const uint32_t cand = wave == 0 ? gt.i1 : gt.i2;
                             uint32_t res = 0;
                             if (cand != NONE) {
+                                // its word was evaluated when the list was priced: find the entry, take the path
+                                uint32_t gsel = 0;
+                                for (uint32_t g0 = 0; g0 < T; g0 += 64) {
+                                    const unsigned long long m = __ballot(g0 + (uint32_t)lane < T && pk_idx[g0 + (uint32_t)lane] == cand);
+                                    if (m) {
+                                        gsel = g0 + (uint32_t)__builtin_ctzll(m);
+                                        break;
+                                    }
+                                }
+                                const double *dp = dpath + (size_t)gsel * 5;
+                                dub_path_t pth;
+                                pth.t = dp[0];
+                                pth.p = dp[1];
+                                pth.q = dp[2];
+                                pth.len = dp[3];
+                                pth.word = (int32_t)dp[4];
                                 int cc = 0;
-                                const bool ok = edge_free(cand, cc);  // rrt.py:519
+                                const bool ok = dub_sweep_wave(og, dc, node_xy(cand), node_h(cand), xq, pth, lane, cc);  // rrt.py:519
                                 res = (ok ? 0x80000000u : 0u) | (uint32_t)cc;
                             }
                             if (lane == 0) dub_slot[2 * NWAVE - 2 + wave].w = res;  // (the .w words of the last two slots are free)
