@@ -111,7 +111,11 @@ RRT_DUB_FN double dub_atan01(double z) {
 RRT_DUB_FN double dub_atan2(double y, double x) {
     const double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
     if (ax == 0.0 && ay == 0.0) return 0.0;
-    double a = (ay <= ax) ? dub_atan01(ay / ax) : 1.5707963267948966 - dub_atan01(ax / ay);
+    /* ONE quotient and ONE series whichever octant (the same operations on the same operands as two calls behind a branch,
+     * but a wavefront whose lanes disagree about the octant no longer runs the 21-term series twice) */
+    const int steep = !(ay <= ax);
+    const double t = dub_atan01((steep ? ax : ay) / (steep ? ay : ax));
+    double a = steep ? 1.5707963267948966 - t : t;
     if (x < 0.0) a = DUB_PI - a;
     return y < 0.0 ? -a : a;
 }
@@ -149,10 +153,14 @@ RRT_DUB_FN dub_path_t dub_shortest(double x0, double y0, double th0, double x1, 
     best.t = best.p = best.q = 0.0;
     best.len = HUGE_VAL;
     best.word = DUB_NONE;
+    /* two arctangents serve four words: LSL and LRL turn about the same pair of circles, RSR and RLR too.  dub_atan2 is odd in
+     * y except at y = 0 (where it returns its value for +0 whatever the sign), so LRL's angle is LSL's negated or, for equal
+     * cosines, LSL's itself: the very values the four separate calls returned */
+    const double at_l = dub_atan2(cb - ca, d + sa - sb), at_r = dub_atan2(ca - cb, d - sa + sb);
     { /* LSL */
         const double psq = 2.0 + dsq - 2.0 * cab + 2.0 * d * (sa - sb);
         if (psq >= 0.0) {
-            const double tmp = dub_atan2(cb - ca, d + sa - sb);
+            const double tmp = at_l;
             dub_take(&best, DUB_LSL, dub_mod2pi(tmp - alpha), sqrt(psq), dub_mod2pi(beta - tmp));
         }
     }
@@ -175,14 +183,14 @@ RRT_DUB_FN dub_path_t dub_shortest(double x0, double y0, double th0, double x1, 
     { /* RSR */
         const double psq = 2.0 + dsq - 2.0 * cab + 2.0 * d * (sb - sa);
         if (psq >= 0.0) {
-            const double tmp = dub_atan2(ca - cb, d - sa + sb);
+            const double tmp = at_r;
             dub_take(&best, DUB_RSR, dub_mod2pi(alpha - tmp), sqrt(psq), dub_mod2pi(tmp - beta));
         }
     }
     { /* RLR */
         const double tmp = (6.0 - dsq + 2.0 * cab + 2.0 * d * (sa - sb)) / 8.0;
         if (tmp <= 1.0 && tmp >= -1.0) {
-            const double phi = dub_atan2(ca - cb, d - sa + sb);
+            const double phi = at_r;
             const double p = dub_mod2pi(DUB_TWOPI - dub_acos(tmp));
             const double t = dub_mod2pi(alpha - phi + dub_mod2pi(p / 2.0));
             dub_take(&best, DUB_RLR, t, p, dub_mod2pi(alpha - beta - t + dub_mod2pi(p)));
@@ -191,7 +199,7 @@ RRT_DUB_FN dub_path_t dub_shortest(double x0, double y0, double th0, double x1, 
     { /* LRL */
         const double tmp = (6.0 - dsq + 2.0 * cab + 2.0 * d * (sb - sa)) / 8.0;
         if (tmp <= 1.0 && tmp >= -1.0) {
-            const double phi = dub_atan2(ca - cb, d + sa - sb);
+            const double phi = (ca - cb == 0.0) ? at_l : -at_l; /* = dub_atan2(ca - cb, d + sa - sb) */
             const double p = dub_mod2pi(DUB_TWOPI - dub_acos(tmp));
             const double t = dub_mod2pi(-alpha - phi + p / 2.0);
             dub_take(&best, DUB_LRL, t, p, dub_mod2pi(dub_mod2pi(beta) - alpha - t + dub_mod2pi(p)));
@@ -239,7 +247,52 @@ typedef struct {
     double x2, y2, th2; /* pose after the second segment */
     int32_t k0, k1, k2; /* segment kinds */
     int32_t nsamples;   /* samples at k * DUB_DS, k = 0 .. nsamples - 1 (the end pose is one more, tested as the goal cell) */
+    double sn0, cs0, sn1, cs1, sn2, cs2; /* sin / cos of the heading at the start of each segment (what dub_advance computes first) */
 } dub_sweep_t;
+
+/* dub_advance with the sine and cosine of th given, position only.  Both arc directions go through ONE dub_sincos call: adding
+ * sg * tau and sg * (difference) with sg = +-1 is exactly the subtraction dub_advance writes for a right arc, so the values are
+ * the same bit for bit, and a wavefront whose samples lie on different segments evaluates one series, not one per branch. */
+RRT_DUB_FN void dub_advance_pre(double x, double y, double th, double s0, double c0, int32_t kind, double tau, double *ox, double *oy) {
+    if (kind == 0) {
+        *ox = x + c0 * tau;
+        *oy = y + s0 * tau;
+        return;
+    }
+    const double sg = kind > 0 ? 1.0 : -1.0;
+    double s1, c1;
+    dub_sincos(th + sg * tau, &s1, &c1);
+    *ox = x + sg * (s1 - s0);
+    *oy = y - sg * (c1 - c0);
+}
+
+/* dub_advance with sin / cos of th given and sin / cos of the new heading returned */
+RRT_DUB_FN void dub_advance_sc(double x, double y, double th, double s0, double c0, int32_t kind, double tau, double *ox, double *oy, double *oth,
+                               double *os, double *oc) {
+    if (kind == 0) {
+        *ox = x + c0 * tau;
+        *oy = y + s0 * tau;
+        *oth = th;
+        *os = s0;
+        *oc = c0;
+    } else if (kind > 0) {
+        double s1, c1;
+        dub_sincos(th + tau, &s1, &c1);
+        *ox = x + (s1 - s0);
+        *oy = y - (c1 - c0);
+        *oth = th + tau;
+        *os = s1;
+        *oc = c1;
+    } else {
+        double s1, c1;
+        dub_sincos(th - tau, &s1, &c1);
+        *ox = x - (s1 - s0);
+        *oy = y + (c1 - c0);
+        *oth = th - tau;
+        *os = s1;
+        *oc = c1;
+    }
+}
 
 RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const dub_path_t *path, double rho) {
     dub_sweep_t s;
@@ -253,8 +306,11 @@ RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const d
     s.k0 = dub_seg_kind(path->word, 0);
     s.k1 = dub_seg_kind(path->word, 1);
     s.k2 = dub_seg_kind(path->word, 2);
-    dub_advance(0.0, 0.0, th0, s.k0, s.t, &s.x1, &s.y1, &s.th1);
-    dub_advance(s.x1, s.y1, s.th1, s.k1, s.p, &s.x2, &s.y2, &s.th2);
+    /* the two junction poses as dub_advance gives them; the sine and cosine of a junction's heading are the ones the advance
+     * that reaches it has just evaluated (same argument), so three series serve the whole set-up */
+    dub_sincos(th0, &s.sn0, &s.cs0);
+    dub_advance_sc(0.0, 0.0, th0, s.sn0, s.cs0, s.k0, s.t, &s.x1, &s.y1, &s.th1, &s.sn1, &s.cs1);
+    dub_advance_sc(s.x1, s.y1, s.th1, s.sn1, s.cs1, s.k1, s.p, &s.x2, &s.y2, &s.th2, &s.sn2, &s.cs2);
     s.nsamples = (int32_t)floor(path->len / DUB_DS) + 1;
     return s;
 }
@@ -262,14 +318,27 @@ RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const d
 /* grid cell of sample k (arc length k * DUB_DS from the start) */
 RRT_DUB_FN void dub_sweep_cell(const dub_sweep_t *s, int32_t k, int32_t *cx, int32_t *cy) {
     const double tau = ((double)k * DUB_DS) / s->rho; /* normalised arc length */
-    double x, y, th;
-    if (tau < s->t)
-        dub_advance(0.0, 0.0, s->th0, s->k0, tau, &x, &y, &th);
-    else if (tau < s->t + s->p)
-        dub_advance(s->x1, s->y1, s->th1, s->k1, tau - s->t, &x, &y, &th);
-    else
-        dub_advance(s->x2, s->y2, s->th2, s->k2, tau - (s->t + s->p), &x, &y, &th);
-    (void)th;
+    /* the segment the sample lies on is selected first, then ONE advance (same operands as one call per branch) */
+    double bx = s->x2, by = s->y2, bth = s->th2, bs = s->sn2, bc = s->cs2, dt = tau - (s->t + s->p), x, y;
+    int32_t kind = s->k2;
+    if (tau < s->t) {
+        bx = 0.0;
+        by = 0.0;
+        bth = s->th0;
+        bs = s->sn0;
+        bc = s->cs0;
+        kind = s->k0;
+        dt = tau;
+    } else if (tau < s->t + s->p) {
+        bx = s->x1;
+        by = s->y1;
+        bth = s->th1;
+        bs = s->sn1;
+        bc = s->cs1;
+        kind = s->k1;
+        dt = tau - s->t;
+    }
+    dub_advance_pre(bx, by, bth, bs, bc, kind, dt, &x, &y);
     *cx = (int32_t)floor(s->x0 + x * s->rho + 0.5);
     *cy = (int32_t)floor(s->y0 + y * s->rho + 0.5);
 }

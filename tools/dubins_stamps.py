@@ -1,0 +1,27 @@
+import sys, os, math
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+import numpy as np
+from rrtplanner_amd import _ffi, hostprep
+from rrtplanner_amd.oggen import perlin_occupancygrid, random_connected_pair
+grid, n = 2048, 100000
+og = perlin_occupancygrid(grid, grid, seed=1)
+og8 = hostprep.og_nonzero(og)
+xs, xg = random_connected_pair(og, np.random.default_rng(11))
+rng = np.random.default_rng(3)
+samples = hostprep.draw_free_samples(rng, np.argwhere(og8 == 0), n)
+heads = rng.integers(0, 64, size=n)
+ctx = _ffi.Context(0); ctx.set_grid(og8)
+b = _ffi.Batch(ctx, 1, n, dubins=True)
+q, keep = _ffi.make_query(_ffi.ALG_DUBINS_STAR, n, (int(xs[0]), int(xs[1]), 5), (int(xg[0]), int(xg[1]), 20), samples, r2_rewire=hostprep.radius_threshold(64), headings=heads, rho=8.0, nh=64)
+b.set_query(0, q)
+for rep in range(2):
+    b.rearm(); b.launch(); b.sync()
+ms = b.elapsed_ms()
+r = b.get_result(0, arrays=False)
+cyc = b.debug_cycles(0)
+print("kernel %.1f ms, j=%d, %.0f cyc/iter (at 2.4 GHz)" % (ms, r.c.j, ms * 2.4e6 / n))
+names = ["A scan", "pricing (wave 0's entries)", "wait for the nearest's word + sweep", "acceptance, test rounds", "D insert", "go2goal"]
+tot = sum(cyc[:6]) or 1
+for nm, c in zip(names, cyc[:6]): print("  %-32s %12d  %5.1f%%  %8.1f cyc/iter" % (nm, c, 100 * c / tot, c / n))
+print("near", r.c.sum_near / n, "los_cand", r.c.n_los_cand / n)
