@@ -601,6 +601,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                         dp[4] = (double)pth.word;
                     }
                 }
+                STAMP(1);  // (diagnostic build: this wave's share of the pricing)
                 if (wave == NWAVE - 1) {  // the nearest node: its word, the cost through it, its sweep (rrt.py:422-424)
                     const uint32_t a = node_xy(vn);
                     const int ha = node_h(vn);
@@ -614,6 +615,7 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
                     }
                 }
                 __syncthreads();
+                STAMP(2);  // (diagnostic build: the wait for the nearest node's word and sweep)
                 const bool nocoll = dub_nn.ok != 0u;
                 const int cells = (int)dub_nn.cells;
                 const double cnear = dub_nn.cost;

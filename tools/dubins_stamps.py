@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader cycles of the Dubins kernel (rrt_expand_kernel<false, true>, wave 0 of one query) from the stamped build.
+
+    make -C rrtplanner_amd/csrc ../librrt_hip_stamps.so
+    RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so python tools/dubins_stamps.py
+
+BASELINE config 5's shape (2048 x 2048, n = 100 000, r_rewire = 64, rho = 8, 64 headings), one query.  Never quote the stamped
+build's run time; read the shares."""
 import sys, os, math
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
