@@ -105,6 +105,7 @@ typedef struct rrt_result {
     int64_t n_rewired;    /* RRT_FLAG_REWIRE: nodes re-parented / descendant costs recomputed (0 otherwise: rrt.py:536 is never true) */
     int64_t n_propagated;
     int32_t *head;        /* Dubins planners: (n+1) heading index of every node; NULL to skip */
+    int64_t n_words;      /* Dubins planners: shortest-word evaluations the device made (0 otherwise) */
 } rrt_result;
 
 /* ---- context / grid -------------------------------------------------------------- */
@@ -143,6 +144,9 @@ int rrt_batch_sync(rrt_batch *b);
 int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fallbacks);
 /* 1 if the last launch ran the pipelined team kernel (one more CU per query, which only commits) */
 int rrt_batch_pipelined(rrt_batch *b, int32_t *pipelined);
+/* name of the expansion kernel the last launch ran (the one before it, for a batch not launched yet: the one it would run),
+ * as rocprofv3 prints it: "rrt_expand_block_kernel<64, 1, true, false>"; buf receives at most len - 1 characters */
+int rrt_batch_kernel_name(rrt_batch *b, char *buf, int32_t len);
 int rrt_batch_elapsed_ms(rrt_batch *b, float *ms); /* HIP events around the last launch's kernels (incl. a launch that timed out) */
 int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out);
 /* diagnostic builds (-DRRT_STAMPS): shader cycles wave 0 of query q spent in scan / barrier / nearest+line of sight /
@@ -164,10 +168,13 @@ int rrt_comm_destroy(rrt_ctx *ctx);
 /* vals[0..count) := reduction over all ranks (op 0 sum, 1 max, 2 min), count <= 64; synchronous: also the barrier */
 int rrt_comm_allreduce_f64(rrt_ctx *ctx, double *vals, int32_t count, int32_t op);
 /* ncclAllGather of the batch's result slab on the context's stream (asynchronous): rank r's slab lands at
- * gathered_dev + r * bytes_per_rank on every rank.  Every rank must bring a batch of the same Q and capacity. */
+ * gathered_dev + r * bytes_per_rank on every rank.  Every rank must bring a batch of the same Q and capacity: checked by a
+ * 16-byte all-reduce in front of every gather (RRT_E_COMM on all ranks when the sizes differ). */
 int rrt_gather(rrt_batch *b, void **gathered_dev, int64_t *bytes_per_rank);
-/* after rrt_gather: query q of rank `rank` from the gathered slabs into caller-allocated host arrays (pts / vcost / parent
- * with n+1 rows as in rrt_batch_get_result; status, j, vgoal, found are filled; logs and statistics are not gathered) */
+/* after rrt_gather ON THIS BATCH (the slabs of another batch, even one of equal size, are refused): query q of rank `rank` from
+ * the gathered slabs into caller-allocated host arrays.  On entry out->rows is the CAPACITY of pts / vcost / parent in rows (the
+ * remote query's row count is only known from its slab: RRT_E_ARG when it exceeds the capacity, nothing is written then); on
+ * return rows = rows written; status, j, vgoal, found are filled; logs and statistics are not gathered */
 int rrt_gather_fetch(rrt_batch *b, int32_t rank, int32_t q, rrt_result *out);
 
 /* ---- one-shot wrappers (what plan() binds) --------------------------------------------- */

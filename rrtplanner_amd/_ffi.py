@@ -54,7 +54,7 @@ SYMBOLS = (
     "rrt_grid_generation", "rrt_ctx_sync",
     "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_comm_allreduce_f64", "rrt_gather", "rrt_gather_fetch",
     "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
-    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_pipelined", "rrt_batch_elapsed_ms",
+    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_pipelined", "rrt_batch_kernel_name", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
     "rrt_plan", "rrt_plan_resume", "rrt_plan_batch",
     "rrt_prim_collisionfree", "rrt_prim_nearest_within", "rrt_prim_sqrt_u32", "rrt_prim_sqrt_u24", "rrt_prim_sqrt_f64",
@@ -88,6 +88,7 @@ class Result(C.Structure):
         ("sum_j", C.c_int64), ("sum_cells_nn", C.c_int64), ("sum_near", C.c_int64), ("sum_cells_cand", C.c_int64),
         ("n_los_cand", C.c_int64), ("n_rewired", C.c_int64), ("n_propagated", C.c_int64),
         ("head", C.c_void_p),
+        ("n_words", C.c_int64),
     ]
 
 
@@ -129,6 +130,7 @@ def lib():
             "rrt_batch_sync": ([vp], C.c_int),
             "rrt_batch_team": ([vp, C.POINTER(i32), C.POINTER(i32)], C.c_int),
             "rrt_batch_pipelined": ([vp, C.POINTER(i32)], C.c_int),
+            "rrt_batch_kernel_name": ([vp, C.c_char_p, i32], C.c_int),
             "rrt_batch_elapsed_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
             "rrt_batch_get_result": ([vp, i32, C.POINTER(Result)], C.c_int),
             "rrt_batch_result_block": ([vp, C.POINTER(vp), C.POINTER(i64)], C.c_int),
@@ -191,7 +193,7 @@ class ResultArrays:
 
     def __getattr__(self, k):  # scalars live in the C struct
         if k in ("status", "j", "vgoal", "found", "i_switch", "rows", "sum_j", "sum_cells_nn", "sum_near",
-                 "sum_cells_cand", "n_los_cand", "n_rewired", "n_propagated"):
+                 "sum_cells_cand", "n_los_cand", "n_rewired", "n_propagated", "n_words"):
             return getattr(self.c, k)
         raise AttributeError(k)
 
@@ -422,6 +424,12 @@ class Batch:
         _check(self.ctx.handle, lib().rrt_batch_pipelined(self._h, C.byref(v)))
         return bool(v.value)
 
+    def kernel_name(self):
+        """the expansion kernel of the last launch, as rocprofv3 names it"""
+        buf = C.create_string_buffer(128)
+        _check(self.ctx.handle, lib().rrt_batch_kernel_name(self._h, buf, 128))
+        return buf.value.decode()
+
     def elapsed_ms(self):
         ms = C.c_float(0)
         _check(self.ctx.handle, lib().rrt_batch_elapsed_ms(self._h, C.byref(ms)))
@@ -454,8 +462,11 @@ class Batch:
         _check(self.ctx.handle, lib().rrt_gather(self._h, C.byref(p), C.byref(nbytes)))
         return p.value, nbytes.value
 
-    def gather_fetch(self, rank, q, n=None):
-        """Query q of rank `rank` out of the gathered slabs (host arrays; status / j / vgoal / found filled)."""
-        res = ResultArrays(self.n_cap if n is None else int(n))
+    def gather_fetch(self, rank, q):
+        """Query q of rank `rank` out of the gathered slabs (host arrays; status / j / vgoal / found filled).  The arrays
+        always hold the batch's full capacity (n_cap + 1 rows): how many rows the remote query has is only known from its
+        slab, and the C side refuses to write more rows than `rows` announces."""
+        res = ResultArrays(self.n_cap)
+        res.c.rows = self.n_cap + 1
         _check(self.ctx.handle, lib().rrt_gather_fetch(self._h, int(rank), int(q), C.byref(res.c)))
         return res

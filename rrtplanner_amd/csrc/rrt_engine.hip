@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>  // types only: the library is opened on demand (rrt_comm_init), the single-GPU path never loads it
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -11,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "rrt_hip.h"
@@ -21,6 +23,33 @@
 using namespace rrtdev;
 
 static thread_local std::string g_last_error;
+
+// Host copy of a batch's query descriptors in page-locked memory: the per-step copies to and from the device (rrt_batch_rearm,
+// rrt_batch_sync) are then plain DMA transfers in stream order, with no staging copy and no hidden synchronisation.
+struct PinnedDescs {
+    QDesc *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(QDesc), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        n = count;
+        for (size_t k = 0; k < n; ++k) p[k] = QDesc{};
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    QDesc *data() { return p; }
+    QDesc *begin() { return p; }
+    QDesc *end() { return p + n; }
+    QDesc &operator[](size_t k) { return p[k]; }
+};
 
 struct rrt_ctx {
     int device = 0;
@@ -41,6 +70,7 @@ struct rrt_ctx {
     int32_t comm_rank = 0, comm_world = 1;
     unsigned char *gather_buf = nullptr;  // [world][slab bytes of the batch gathered last]
     size_t gather_bytes = 0;
+    const rrt_batch *gather_owner = nullptr;  // the batch whose slabs gather_buf holds (rrt_gather_fetch serves no other)
     double *d_red = nullptr;  // small device scratch of rrt_comm_allreduce_f64
 };
 
@@ -55,11 +85,14 @@ struct rrt_batch {
     int32_t team = 1;           // workgroups (CUs) per query of the block kernel that scan and resolve (rrt_block.h, teams)
     bool pipe_team = false;     // the team is pipelined: one more workgroup per query, which only commits
     bool pipe = false;          // the last launch ran the pipelined team kernel
+    int32_t last_team = 0;      // workers per query of the last launch (1 after a hand-off timed out)
+    bool last_inf = false;      // the last launch ran the Informed instantiation
     int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
     int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
     unsigned char *d_team = nullptr;  // [Q][TEAM_BYTES] sync words, state, exchanged records; zeroed before every launch
     QDesc *d_desc = nullptr;
-    std::vector<QDesc> h_desc;
+    PinnedDescs h_desc;  // page-locked
+    size_t serial_lds_static = 0;  // static LDS of the one-sample-per-iteration kernel + 1 (0 = not asked yet)
     uint32_t *d_samples = nullptr, *d_nodes = nullptr, *d_bitmap = nullptr;
     double *d_vcost = nullptr, *d_unitball = nullptr, *d_cbest_log = nullptr;
     int32_t *d_parent = nullptr, *d_nearest_log = nullptr, *d_j_log = nullptr;
@@ -87,6 +120,25 @@ struct rrt_batch {
 static const void *block_kernel_of(int team, bool pipe, bool inf);
 static size_t block_kernel_static_lds(int team);
 
+// The limit is a property of the kernel on a device, shared by every batch that launches it: it is only ever raised, to the
+// largest request seen, and hipFuncSetAttribute is called when a launch needs more than the kernel already has -- once per
+// kernel and size in practice, instead of once per launch.
+static hipError_t raise_dynamic_lds(int device, const void *kern, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::tuple<int, const void *, int>> have;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &t : have)
+        if (std::get<0>(t) == device && std::get<1>(t) == kern) {
+            if (std::get<2>(t) >= bytes) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess) std::get<2>(t) = bytes;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) have.emplace_back(device, kern, bytes);
+    return e;
+}
+
 static int fail(rrt_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -103,6 +155,20 @@ static int fail(rrt_ctx *ctx, int code, const char *fmt, ...) {
         hipError_t e_ = (call);                                                                        \
         if (e_ != hipSuccess) return fail(ctx, RRT_E_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
     } while (0)
+
+// Wait for the context's stream by polling (no interrupt wake-up of a sleeping host thread: on a host that parks the waiting
+// thread the default wait costs up to a millisecond per step, against a 9 ms launch).  A wait that lasts longer than
+// `spin_ms` falls through to the blocking wait, where the wake-up no longer matters and a spinning core would.
+static hipError_t wait_stream_spin(hipStream_t stream, double spin_ms = 100.0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; ++it) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e;
+        if ((it & 1023u) == 1023u && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > spin_ms)
+            return hipStreamSynchronize(stream);
+        __builtin_ia32_pause();
+    }
+}
 
 // device temporaries of one call: freed on every return path
 struct DevTmp {
@@ -358,6 +424,8 @@ extern "C" int rrt_batch_destroy(rrt_batch *b) {
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->ctx->single == b) b->ctx->single = nullptr;
+    if (b->ctx->gather_owner == b) b->ctx->gather_owner = nullptr;
+    b->h_desc.release();
     delete b;
     return RRT_OK;
 }
@@ -435,7 +503,10 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     }
     b->lds_chunks = chunks < 1 ? 1 : (chunks > MAX_LDS_CHUNKS ? MAX_LDS_CHUNKS : chunks);
     if ((flags & RRT_FLAG_DUBINS) && b->lds_chunks > 5) b->lds_chunks = 5;  // the Dubins kernel keeps the packed near set (36 KiB) in LDS too
-    b->h_desc.assign((size_t)Q, QDesc{});
+    if (hipError_t e_ = b->h_desc.alloc((size_t)Q); e_ != hipSuccess) {
+        rrt_batch_destroy(b);
+        return fail(ctx, RRT_E_HIP, "hipHostMalloc(%zu): %s", (size_t)Q * sizeof(QDesc), hipGetErrorString(e_));
+    }
     for (auto &d : b->h_desc) d.status = ST_IDLE;
     const size_t q = (size_t)Q;
 #define ALLOC(ptr, bytes)                                   \
@@ -505,6 +576,7 @@ static void arm_desc(QDesc &d) {
     d.ub_count = 0;
     d.sum_j = d.sum_cells_nn = d.sum_near = d.sum_cells_cand = d.n_los_cand = 0;
     d.n_rewired = d.n_propagated = 0;
+    d.n_words = 0;
     for (auto &c : d.cyc) c = 0;
     for (auto &c : d.wcyc) c = 0;
 }
@@ -517,6 +589,7 @@ extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu)
     const bool dub = qu->alg >= RRT_ALG_DUBINS;
     if (dub != ((b->flags & RRT_FLAG_DUBINS) != 0))
         return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: alg=%d on a batch created %s RRT_FLAG_DUBINS", qu->alg, dub ? "without" : "with");
+    if (qu->n < 1 || qu->n > b->n_cap) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: n=%d, capacity %d", qu->n, b->n_cap);
     if (dub) {
         if (!qu->headings || !(qu->rho > 0.0) || !std::isfinite(qu->rho) || qu->nh < 1 || qu->nh > 256 || qu->hs < 0 || qu->hs >= qu->nh ||
             qu->hg < 0 || qu->hg >= qu->nh)
@@ -524,7 +597,6 @@ extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu)
         for (int k = 0; k < qu->n; ++k)
             if (qu->headings[k] < 0 || qu->headings[k] >= qu->nh) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: heading of sample %d outside [0, %d)", k, qu->nh);
     }
-    if (qu->n < 1 || qu->n > b->n_cap) return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: n=%d, capacity %d", qu->n, b->n_cap);
     if (b->gridW != ctx->W || b->gridH != ctx->H)
         return fail(ctx, RRT_E_ARG, "rrt_batch_set_query: grid changed shape since rrt_batch_create");
     const int W = ctx->W, H = ctx->H;
@@ -725,9 +797,11 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
 #endif
         b->pipe = pipe;
         bool inf = false;  // any Informed query in this launch?
-        for (const auto &d : b->h_desc)
+        for (const QDesc &d : b->h_desc)
             if (d.status == ST_RUNNING && d.alg == 2) inf = true;
-        HIPCHK(ctx, hipFuncSetAttribute(block_kernel_of(team, pipe, inf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_lds_bytes));
+        b->last_team = team;
+        b->last_inf = inf;
+        HIPCHK(ctx, raise_dynamic_lds(ctx->device, block_kernel_of(team, pipe, inf), (int)blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         if (team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
@@ -743,11 +817,14 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     const serial_kernel_fn kern = (b->flags & RRT_FLAG_DUBINS)  ? static_cast<serial_kernel_fn>(rrt_expand_kernel<false, true>)
                                   : (b->flags & RRT_FLAG_REWIRE) ? static_cast<serial_kernel_fn>(rrt_expand_kernel<true, false>)
                                                                  : static_cast<serial_kernel_fn>(rrt_expand_kernel<false, false>);
-    hipFuncAttributes fa{};
-    HIPCHK(ctx, hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
-    const size_t lds_static = fa.sharedSizeBytes;
+    if (b->serial_lds_static == 0) {
+        hipFuncAttributes fa{};
+        HIPCHK(ctx, hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
+        b->serial_lds_static = fa.sharedSizeBytes + 1;
+    }
+    const size_t lds_static = b->serial_lds_static - 1;
     if ((int)(lds + lds_static) > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds + lds_static, ctx->max_lds);
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(ctx, raise_dynamic_lds(ctx->device, reinterpret_cast<const void *>(kern), (int)lds));
     hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
     hipLaunchKernelGGL(kern, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
@@ -762,7 +839,7 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
     rrt_ctx *ctx = b->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(b->h_desc.data(), b->d_desc, (size_t)b->Q * sizeof(QDesc), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, wait_stream_spin(ctx->stream));
     // A team whose members were not resident together stops at a block boundary with a consistent tree (ST_TEAM_FAIL, a
     // bounded wait expired).  Teams are only an optimisation: the batch continues from there with one CU per query.
     bool team_fail = false;
@@ -781,7 +858,7 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
         int rc = rrt_batch_launch(b);
         if (rc != RRT_OK) return rc;
         HIPCHK(ctx, hipMemcpyAsync(b->h_desc.data(), b->d_desc, (size_t)b->Q * sizeof(QDesc), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, wait_stream_spin(ctx->stream));
     }
     return RRT_OK;
 }
@@ -796,6 +873,20 @@ extern "C" int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fal
 extern "C" int rrt_batch_pipelined(rrt_batch *b, int32_t *pipelined) {
     if (!b || !pipelined) return fail(nullptr, RRT_E_ARG, "rrt_batch_pipelined: NULL");
     *pipelined = (b->use_block && b->team > 1 && b->pipe) ? 1 : 0;
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_kernel_name(rrt_batch *b, char *buf, int32_t len) {
+    if (!b || !buf || len < 1) return fail(nullptr, RRT_E_ARG, "rrt_batch_kernel_name: bad argument");
+    char tmp[96];
+    if (b->use_block) {
+        const int team = b->last_team > 0 ? b->last_team : b->team;
+        const int bsm = team <= 4 ? 16 : 64 / team;
+        snprintf(tmp, sizeof tmp, "rrt_expand_block_kernel<%d, %d, %s, %s>", team, bsm, (team > 1 && b->pipe) ? "true" : "false", b->last_inf ? "true" : "false");
+    } else {
+        snprintf(tmp, sizeof tmp, "rrt_expand_kernel<%s, %s>", (b->flags & RRT_FLAG_REWIRE) ? "true" : "false", (b->flags & RRT_FLAG_DUBINS) ? "true" : "false");
+    }
+    snprintf(buf, (size_t)len, "%s", tmp);
     return RRT_OK;
 }
 
@@ -828,6 +919,7 @@ extern "C" int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out) {
     out->n_los_cand = (int64_t)d.n_los_cand;
     out->n_rewired = (int64_t)d.n_rewired;
     out->n_propagated = (int64_t)d.n_propagated;
+    out->n_words = (int64_t)d.n_words;
     const int live = d.j + (d.found ? 1 : 0);
     if (out->pts) {
         std::vector<uint32_t> tmp((size_t)live);
@@ -980,6 +1072,7 @@ extern "C" int rrt_comm_destroy(rrt_ctx *ctx) {
     ctx->gather_buf = nullptr;
     ctx->d_red = nullptr;
     ctx->gather_bytes = 0;
+    ctx->gather_owner = nullptr;
     ctx->comm_rank = 0;
     ctx->comm_world = 1;
     return RRT_OK;
@@ -1012,12 +1105,17 @@ extern "C" int rrt_gather(rrt_batch *b, void **gathered_dev, int64_t *bytes_per_
     if (!ctx->comm) return fail(ctx, RRT_E_COMM, "rrt_gather: call rrt_comm_init first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t need = b->slab_bytes * (size_t)ctx->comm_world;
-    if (ctx->gather_bytes != need) {
-        // every rank must bring a slab of the same size (same Q and capacity): checked once per buffer size
+    ctx->gather_owner = nullptr;
+    {
+        // Every rank must bring a slab of the same size (same Q and capacity).  The check is itself a collective, so it runs in
+        // EVERY rrt_gather on every rank -- never conditionally on this rank's own cache state, which would let one rank enter
+        // the all-reduce while another enters the all-gather.  It costs one 16-byte all-reduce per gather.
         double mm[2] = {(double)b->slab_bytes, -(double)b->slab_bytes};
         int rc = rrt_comm_allreduce_f64(ctx, mm, 2, 1);
         if (rc != RRT_OK) return rc;
         if (mm[0] != -mm[1]) return fail(ctx, RRT_E_COMM, "rrt_gather: ranks hold result slabs of different sizes (%.0f .. %.0f bytes)", -mm[1], mm[0]);
+    }
+    if (ctx->gather_bytes != need) {
         if (ctx->gather_buf) HIPCHK(ctx, hipFree(ctx->gather_buf));
         ctx->gather_buf = nullptr;
         ctx->gather_bytes = 0;
@@ -1028,6 +1126,7 @@ extern "C" int rrt_gather(rrt_batch *b, void **gathered_dev, int64_t *bytes_per_
     hipLaunchKernelGGL(slab_meta_kernel, dim3((unsigned)((b->Q + 63) / 64)), dim3(64), 0, ctx->stream, b->d_desc, b->Q, meta);
     HIPCHK(ctx, hipGetLastError());
     RCCLCHK(ctx, g_rccl.AllGather(b->d_slab, ctx->gather_buf, b->slab_bytes, ncclUint8, ctx->comm, ctx->stream));
+    ctx->gather_owner = b;
     if (gathered_dev) *gathered_dev = ctx->gather_buf;
     if (bytes_per_rank) *bytes_per_rank = (int64_t)b->slab_bytes;
     return RRT_OK;
@@ -1036,8 +1135,8 @@ extern "C" int rrt_gather(rrt_batch *b, void **gathered_dev, int64_t *bytes_per_
 extern "C" int rrt_gather_fetch(rrt_batch *b, int32_t rank, int32_t q, rrt_result *out) {
     if (!b || !out) return fail(nullptr, RRT_E_ARG, "rrt_gather_fetch: NULL");
     rrt_ctx *ctx = b->ctx;
-    if (!ctx->gather_buf || ctx->gather_bytes != b->slab_bytes * (size_t)ctx->comm_world)
-        return fail(ctx, RRT_E_COMM, "rrt_gather_fetch: call rrt_gather on this batch first");
+    if (!ctx->gather_buf || ctx->gather_owner != b || ctx->gather_bytes != b->slab_bytes * (size_t)ctx->comm_world)
+        return fail(ctx, RRT_E_COMM, "rrt_gather_fetch: the gathered slabs are not this batch's (call rrt_gather on this batch first)");
     if (rank < 0 || rank >= ctx->comm_world || q < 0 || q >= b->Q) return fail(ctx, RRT_E_ARG, "rrt_gather_fetch: rank %d, query %d", rank, q);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const unsigned char *slab = ctx->gather_buf + (size_t)rank * b->slab_bytes;
@@ -1051,6 +1150,9 @@ extern "C" int rrt_gather_fetch(rrt_batch *b, int32_t rank, int32_t q, rrt_resul
     out->found = meta[3];
     const int live = meta[1] + (meta[3] ? 1 : 0);
     if (live < 0 || (size_t)live > S) return fail(ctx, RRT_E_COMM, "rrt_gather_fetch: rank %d query %d carries %d rows", rank, q, live);
+    if ((out->pts || out->vcost || out->parent) && live > out->rows)
+        return fail(ctx, RRT_E_ARG, "rrt_gather_fetch: rank %d query %d has %d rows, the caller's arrays hold %d (set out->rows to their capacity)", rank, q, live, out->rows);
+    out->rows = live;
     if (out->pts) {
         std::vector<uint32_t> tmp((size_t)live);
         HIPCHK(ctx, hipMemcpyAsync(tmp.data(), slab + Q * S * 8 + ((size_t)q * S) * 4, (size_t)live * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -48,6 +48,7 @@ struct QDesc {
     unsigned long long n_rewired, n_propagated;  // opt-in true rewire (RRT_FLAG_REWIRE): nodes re-parented, descendant costs recomputed
     double rho;          // Dubins planners (alg 3 / 4): turning radius in cells, number of headings, start / goal heading index
     int32_t nh, hs, hg, pad_;
+    unsigned long long n_words;  // Dubins planners: dub_shortest() evaluations made (the byte / flop model counts one per near-set entry)
 };
 
 struct BatchView {

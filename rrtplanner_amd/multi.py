@@ -31,9 +31,17 @@ def local_slot(q: int, world_size: int) -> int:
 
 
 # ---------------------------------------------------------------------------------- communicator id hand-over
+def _attempt_nonce() -> str:
+    """What distinguishes this launch ATTEMPT from an earlier one under the same launcher: bench.py's own spawner sets
+    RRT_COMM_NONCE per launch; torch.distributed.run sets TORCHELASTIC_RUN_ID and, per worker restart under one agent
+    (--max-restarts), TORCHELASTIC_RESTART_COUNT.  Every rank of one attempt sees the same values."""
+    e = os.environ
+    return "_".join(x for x in (e.get("RRT_COMM_NONCE", ""), e.get("TORCHELASTIC_RUN_ID", ""), e.get("TORCHELASTIC_RESTART_COUNT", "")) if x) or "0"
+
+
 def _launcher_key() -> str:
-    """A name all ranks of one launch on this node agree on and no other launch shares: the launcher's pid and start
-    time (every rank is a child of the same launcher process) plus the rendezvous port."""
+    """A name all ranks of one launch attempt on this node agree on and no other attempt shares: the launcher's pid and
+    start time (every rank is a child of the same launcher process), the rendezvous port and the attempt nonce."""
     ppid = os.getppid()
     start = "0"
     try:
@@ -41,7 +49,8 @@ def _launcher_key() -> str:
             start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time in clock ticks since boot
     except (OSError, IndexError):
         pass
-    return f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}"
+    nonce = "".join(c if c.isalnum() or c in "-_" else "-" for c in _attempt_nonce())[:96]
+    return f"{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}_{nonce}"
 
 
 def _id_paths(path):
@@ -55,44 +64,94 @@ def _id_paths(path):
             os.path.join(base, f"rrt_comm_port_{os.environ.get('MASTER_ADDR', 'local')}_{os.environ.get('MASTER_PORT', '0')}.id"))
 
 
-_T_START = time.time()
+def _process_start_time() -> float:
+    """Epoch seconds at which this process started (not the later moment at which this module was imported: rank 0 may have
+    published the id while a slower rank was still importing numpy)."""
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return time.time() - (up - ticks / os.sysconf("SC_CLK_TCK"))
+    except (OSError, IndexError, ValueError):
+        return time.time()
+
+
+_T_START = _process_start_time()
+_FRESH_SLACK = 30.0  # ranks of one launch start within this many seconds of each other
+
+
+def _publish(target: str, uid: bytes):
+    """Write `uid` to `target` so that a reader sees all of it or nothing, without following a link somebody else planted
+    in the (world-writable) directory: the temporary file is created exclusively, 0600, and renamed over the target."""
+    tmp = f"{target}.{os.getpid()}.{time.time_ns()}.tmp"
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    try:
+        with os.fdopen(fd, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, target)
+    except BaseException:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        raise
+
+
+def _read_fresh(target: str):
+    """The id in `target`, or None when the file is absent, not a regular file of ours, or older than this launch (a file a
+    crashed earlier attempt left behind)."""
+    try:
+        fd = os.open(target, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    except OSError:
+        return None
+    try:
+        st = os.fstat(fd)
+        import stat as _stat
+
+        if not _stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or st.st_mtime < _T_START - _FRESH_SLACK:
+            return None
+        with os.fdopen(os.dup(fd), "rb") as f:
+            uid = f.read()
+        return uid if len(uid) > 0 else None
+    except OSError:
+        return None
+    finally:
+        os.close(fd)
 
 
 def exchange_unique_id(rank: int, world_size: int, make_id, path: str = None, timeout: float = 120.0) -> bytes:
     """Rank 0 calls `make_id()` (-> 128 bytes, ``_ffi.comm_unique_id``) and publishes the result; the other ranks of the
-    node wait for it.  Single node, so a file on local tmpfs is the side channel: written under a temporary name and
-    renamed, so a reader sees all of it or nothing.  Rank 0 removes the files in `release_unique_id` once the
-    communicator exists (ncclCommInitRank returns only after every rank has joined, i.e. has read the id).  The port-keyed
-    fallback is only accepted when it is fresh (written after this process started, give or take a few seconds): a file a
-    crashed earlier run left behind is ignored."""
+    node wait for it.  Single node, so a file on local tmpfs is the side channel.  Rank 0 first removes whatever an earlier
+    attempt left under the same names, publishes, and removes the files again in `release_unique_id` once the communicator
+    exists (ncclCommInitRank returns only after every rank has joined, i.e. has read the id).  A reader accepts a file only
+    when it is a regular file of the same user written after this launch began (give or take `_FRESH_SLACK` seconds), under
+    either name; the name itself carries the launcher's identity and a per-attempt nonce, so a restarted attempt does not
+    even look at its predecessor's file."""
     if world_size < 1 or not (0 <= rank < world_size):
         raise ValueError(f"bad rank {rank} of {world_size}")
     main, fallback = _id_paths(path)
     if rank == 0:
+        for target in (main, fallback):
+            if target is not None:
+                try:
+                    os.unlink(target)
+                except OSError:
+                    pass
         uid = bytes(make_id())
         for target in (main, fallback):
-            if target is None:
-                continue
-            tmp = f"{target}.{os.getpid()}.tmp"
-            with open(tmp, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, target)
+            if target is not None:
+                _publish(target, uid)
         return uid
     t0 = time.monotonic()
     deadline = t0 + timeout
     while True:
-        for target, fresh_only in ((main, False), (fallback, True)):
-            if target is None or (fresh_only and time.monotonic() - t0 < 3.0):  # the fallback only after the shared name stayed absent
+        for target, late in ((main, False), (fallback, True)):
+            if target is None or (late and time.monotonic() - t0 < 3.0):  # the fallback only after the shared name stayed absent
                 continue
-            try:
-                if fresh_only and os.path.getmtime(target) < _T_START - 10.0:
-                    continue
-                with open(target, "rb") as f:
-                    uid = f.read()
-                if len(uid) > 0:
-                    return uid
-            except OSError:
-                pass
+            uid = _read_fresh(target)
+            if uid is not None:
+                return uid
         if time.monotonic() > deadline:
             raise TimeoutError(f"rank {rank}: no communicator id at {main} after {timeout:.0f} s")
         time.sleep(0.01)

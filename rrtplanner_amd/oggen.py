@@ -103,6 +103,18 @@ def random_connected_pair(og: np.ndarray, rnd_gen: np.random.Generator):
     return a, b
 
 
+def random_connected_pairs(og: np.ndarray, rnd_gen: np.random.Generator, count: int):
+    """`count` consecutive ``random_connected_pair`` draws (same generator consumption, same pairs) with the component
+    labelling done once instead of once per pair."""
+    cells = np.argwhere(largest_free_component(og))
+    out = []
+    for _ in range(count):
+        a = cells[rnd_gen.integers(low=0, high=cells.shape[0])]
+        b = cells[rnd_gen.integers(low=0, high=cells.shape[0])]
+        out.append((a, b))
+    return out
+
+
 class DeviceGrids:
     """`frames` seeded noise occupancy grids generated ON THE DEVICE and kept resident in HBM
     (the device-resident counterpart of ``perlin_occupancygrid(w, h, thresh, frames)``, reference oggen.py:7-45).

@@ -139,3 +139,82 @@ def test_unique_id_port_keyed_fallback(tmp_path, monkeypatch):
     monkeypatch.setenv("MASTER_PORT", "45678")
     multi.release_unique_id(0)
     assert not os.path.exists(main) and not os.path.exists(fallback)
+
+
+def test_stale_main_file_is_ignored_and_replaced(tmp_path, monkeypatch):
+    """a file an earlier attempt left under the SAME launcher-keyed name (rank 0 died inside ncclCommInitRank) must
+    not be handed to the other ranks: an old one is refused by its age, and rank 0 removes it before it makes the new id."""
+    import time
+
+    monkeypatch.setenv("RRT_COMM_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "45679")
+    main, fallback = multi._id_paths(None)
+    with open(main, "wb") as f:
+        f.write(b"\xee" * 128)
+    old = time.time() - 3600
+    os.utime(main, (old, old))
+    with pytest.raises(TimeoutError):
+        multi.exchange_unique_id(1, 2, None, timeout=0.5)
+    seen = {}
+
+    def make():
+        seen["stale_gone"] = not os.path.exists(main) and not os.path.exists(fallback)  # nothing readable while the id is being made
+        return bytes(range(128))
+
+    with open(main, "wb") as f:  # a FRESH leftover (an attempt that died seconds ago): only the unlink-before-publish protects
+        f.write(b"\xee" * 128)
+    uid = multi.exchange_unique_id(0, 2, make)
+    assert seen["stale_gone"] and uid == bytes(range(128))
+    assert multi.exchange_unique_id(1, 2, None, timeout=5.0) == uid
+    assert (os.stat(main).st_mode & 0o777) == 0o600
+    multi.release_unique_id(0)
+
+
+def test_attempt_nonce_names_the_file(monkeypatch):
+    """Worker restarts under one torchrun agent (same parent, same port) get different file names."""
+    monkeypatch.setenv("MASTER_PORT", "45680")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run/1")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    k0 = multi._launcher_key()
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    k1 = multi._launcher_key()
+    monkeypatch.setenv("RRT_COMM_NONCE", "abc")
+    k2 = multi._launcher_key()
+    assert len({k0, k1, k2}) == 3 and "/" not in k0 + k1 + k2
+
+
+def test_planted_symlink_is_not_followed(tmp_path):
+    """The id file lives in a world-writable directory: a link planted under its name is neither read nor written through."""
+    victim = tmp_path / "victim"
+    victim.write_bytes(b"\x01" * 128)
+    link = tmp_path / "planted.id"
+    os.symlink(victim, link)
+    with pytest.raises(TimeoutError):
+        multi.exchange_unique_id(1, 2, None, path=str(link), timeout=0.3)
+    uid = multi.exchange_unique_id(0, 2, lambda: bytes(range(128)), path=str(link))
+    assert victim.read_bytes() == b"\x01" * 128 and not os.path.islink(link) and open(link, "rb").read() == uid
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` called plainly (no launcher, no RANK) must start two rank processes itself.  On a box
+    without a GPU each rank fails at its first HIP call: the failure comes from INSIDE the children (rank environment set,
+    library loaded), not from argument checking, and the parent reports the ranks' exit codes."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["RRT_BENCH_ECHO_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-batched", "--n", "500"], env=env, capture_output=True, text=True, timeout=600)
+    err = p.stderr
+    assert "bench rank 0 of 2" in err and "bench rank 1 of 2" in err, err[-2000:]
+    try:
+        import ctypes
+
+        have_gpu = ctypes.CDLL("libamdhip64.so").hipGetDeviceCount(ctypes.byref(ctypes.c_int(0))) == 0
+    except OSError:
+        have_gpu = False
+    if not have_gpu:
+        assert p.returncode != 0 and "rank(s) failed" in err and "librrt_hip error" in err, err[-2000:]
+        assert "launch with" not in err

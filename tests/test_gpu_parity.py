@@ -3,6 +3,7 @@
 Bit-exact for tree topology, node coordinates, collision decisions and edge costs (f64).  Everything
 here calls librrt_hip.so; the oracle is only the checker."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -343,8 +344,9 @@ def test_batch_of_queries_matches_single_queries(gpu_ctx):
 
 def _bench_config4_queries(og, free, Q, n, first=0, stride=1):
     """bench.py's config-4 queries first, first + stride, ...: start/goal from default_rng(7), planner seed = query index."""
-    sg = np.random.default_rng(7)
-    pairs = [random_connected_pair(og, sg) for _ in range(first + stride * Q)]
+    from rrtplanner_amd.oggen import random_connected_pairs
+
+    pairs = random_connected_pairs(og, np.random.default_rng(7), first + stride * Q)
     out = []
     for k in range(Q):
         g = first + stride * k
@@ -394,6 +396,72 @@ def test_config4_share_of_one_gpu_equals_the_oracle(gpu_ctx):
     assert m["xstart"] == [int(v) for v in qs[0][0]] and m["xgoal"] == [int(v) for v in qs[0][1]]
     live = refs[0][1].j + 1
     assert np.array_equal(GBIG.arr(m["id"], "parent")[:live], refs[0][1].parent[:live])
+
+
+def test_config4_shard_of_rank_3_of_8_equals_the_oracle(gpu_ctx):
+    """What rank 3 of an 8-GPU run of BASELINE configs[3] computes (bench.py: query g = rank + world * slot, i.e. queries 3, 11,
+    ... 507 of the 512): its 64 queries as one batch on this GPU, every tree equal to the oracle's.  One GPU cannot run the
+    other seven ranks, but it can run any rank's share."""
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    Q, n, rank, world = 64, 20000, 3, 8
+    r2 = hostprep.radius_threshold(64)
+    from rrtplanner_amd import multi
+
+    assert multi.shard_queries(Q * world, world, rank) == [rank + world * k for k in range(Q)]
+    qs = _bench_config4_queries(og, free, Q, n, first=rank, stride=world)
+    b = _ffi.Batch(gpu_ctx, Q, n)
+    keep = []
+    for q, (xs, xg, samples) in enumerate(qs):
+        qu, k = _ffi.make_query(1, n, xs, xg, samples, r2_rewire=r2)
+        keep.append(k)
+        b.set_query(q, qu)
+    b.launch()
+    b.sync()
+    assert b.team() == (3, 0) and b.pipelined()
+    for q, (xs, xg, samples) in enumerate(qs):
+        st, ro = oracle.plan(og8, n, 1, xs, xg, samples, r2_rewire=r2, logs=False)
+        res = b.get_result(q)
+        live = ro.j + (1 if ro.found else 0)
+        assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal and res.found == ro.found, q
+        assert np.array_equal(res.pts[:live], ro.pts[:live]) and np.array_equal(res.parent[:live], ro.parent[:live]), q
+        assert np.array_equal(res.vcost[:live], ro.vcost[:live]), q
+    b.close()
+
+
+def _run_bench(extra_env, *args):
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout  # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_as_a_rank_and_as_its_own_launcher():
+    """bench.py in the three ways it can be started on a one-GPU box: plainly; as rank 0 of 1 the way a launcher starts it
+    (communicator, gather and max-over-ranks timing in the loop); and the JSON contract of both.  The rate with the collective
+    in the loop stays within a few per cent of the plain run, and no roofline fraction above 1 is printed anywhere."""
+    args = ("--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-batched")
+    plain = _run_bench({}, *args)
+    ranked = _run_bench({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29731"}, *args)
+    for d in (plain, ranked):
+        assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["unit"] == "nodes/s" and d["scaling"] == "weak"
+        r = d["roofline"]
+        assert r["frac"] is None or 0 < r["frac"] <= 1
+        assert r["kernel"].startswith("rrt_expand_block_kernel<64, 1, true")
+        assert d["host_gap_ms"] == pytest.approx(d["ms_per_step"] - r["kernel_ms"]) and d["config"]["team_fallbacks"] == 0
+    assert plain["config"]["collective"] is None and "ncclAllGather" in ranked["config"]["collective"]
+    assert ranked["value"] == pytest.approx(plain["value"], rel=0.06)
+    assert plain["host_gap_ms"] < 0.25, plain  # the step is the kernel: what the host adds stays below a quarter millisecond
 
 
 def test_plan_batch_one_shot(gpu_ctx):
@@ -462,6 +530,20 @@ def test_gather_single_rank_self_test():
         assert np.array_equal(res.vcost[:live], ro.vcost[:live])
     with pytest.raises(_ffi.RRTError):
         b.gather_fetch(1, 0)  # no such rank
+    # a fetch never writes more rows than the caller's arrays hold ...
+    import ctypes as C
+
+    short = _ffi.ResultArrays(10)
+    short.c.rows = 11
+    rc = _ffi.lib().rrt_gather_fetch(b._h, 0, 0, C.byref(short.c))
+    assert rc == _ffi.RRT_E_ARG and not short.pts.any() and not short.vcost.any()
+    # ... and a batch of the same size whose slabs were NOT the ones gathered is refused instead of served another batch's trees
+    b2 = _ffi.Batch(ctx, Q, n)
+    with pytest.raises(_ffi.RRTError) as e2:
+        b2.gather_fetch(0, 0)
+    assert e2.value.code == _ffi.RRT_E_COMM
+    b2.close()
+    assert b.gather_fetch(0, 1).j == refs[1][1].j  # b's own slabs are still served
     b.close()
     ctx.comm_destroy()
     with pytest.raises(_ffi.RRTError) as e:

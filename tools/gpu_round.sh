@@ -2,7 +2,7 @@
 # One GPU-box session: the -m gpu suite, the bench lines and the rocprofv3 passes whose summaries go to profiles/.
 #   gpurun --timeout 1200 -- bash tools/gpu_round.sh [tests|bench|prof|pmc ...]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/r03
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
@@ -10,6 +10,18 @@ for what in "$@"; do
 case $what in
 tests)
     (cd $R && python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1); echo "tests rc=$?"; tail -n 3 $O/gpu_tests.log ;;
+driver)
+    # the driver's exact command line (BENCH_rNN.json)
+    (cd $R && python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err); echo "driver-cmd bench rc=$?"
+    python3 - <<PY
+import json
+d=json.load(open("$O/bench_driver_cmd.json"))
+print("ms_per_step %.3f kernel_ms %.3f host_gap_ms %.3f value %.4g"%(d["ms_per_step"], d["roofline"]["kernel_ms"], d["host_gap_ms"], d["value"]))
+PY
+    ;;
+gap)
+    python3 $R/tools/step_gap.py --steps 20 > $O/step_gap.txt 2>&1; echo "gap rc=$?"; cat $O/step_gap.txt
+    python3 $R/tools/step_gap.py --steps 20 --config 4 >> $O/step_gap.txt 2>&1; tail -n 9 $O/step_gap.txt ;;
 bench)
     python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -n 2 $O/bench_default.err
     RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_PORT=29999 python3 $R/bench.py --no-cpu-baseline --no-batched > $O/bench_one_rank_comm.json 2> $O/bench_one_rank_comm.err; echo "bench(comm) rc=$?"
