@@ -168,6 +168,9 @@ class _DubPlan(C.Structure):
         ("j", C.c_int32), ("vgoal", C.c_int32), ("found", C.c_int32), ("rows", C.c_int32),
         ("sum_j", C.c_int64), ("sum_cells_nn", C.c_int64), ("sum_near", C.c_int64), ("sum_cells_cand", C.c_int64),
         ("n_dubins", C.c_int64),
+        ("counters", C.c_int32), ("pad2_", C.c_int32),
+        ("near_of_rejected", C.c_int64), ("lb_static_skip", C.c_int64), ("lb_evals", C.c_int64), ("lb_sweeps", C.c_int64),
+        ("lb_violations", C.c_int64), ("lb_mismatch", C.c_int64),
     ]
 
 
@@ -211,7 +214,7 @@ def dub_atan2(y, x):
     return _dub_lib().orc_dub_atan2(float(y), float(x))
 
 
-def dubins_plan(og8, n, star, xs, xg, samples, headings, r2_rewire=0, rho=8.0, nh=64, logs=True):
+def dubins_plan(og8, n, star, xs, xg, samples, headings, r2_rewire=0, rho=8.0, nh=64, logs=True, counters=False):
     """Run orc_dubins_plan once: xs / xg are (x, y, heading index).  Returns (status, PlanResult)."""
     og8 = np.ascontiguousarray(og8, dtype=np.uint8)
     samples = np.ascontiguousarray(samples, dtype=np.int32)
@@ -223,6 +226,7 @@ def dubins_plan(og8, n, star, xs, xg, samples, headings, r2_rewire=0, rho=8.0, n
     for k in range(3):
         p.xs[k], p.xg[k] = int(xs[k]), int(xg[k])
     p.r2_rewire, p.rho, p.nh = int(r2_rewire), float(rho), int(nh)
+    p.counters = 1 if counters else 0  # study of the chord lower bound (see dubins_oracle.c), results unchanged
     p.samples, p.headings = samples.ctypes.data, headings.ctypes.data
     r = PlanResult()
     r.pts = np.empty((n + 1, 2), dtype=np.int32)
@@ -235,6 +239,7 @@ def dubins_plan(og8, n, star, xs, xg, samples, headings, r2_rewire=0, rho=8.0, n
         r.accept_log = np.zeros(n, dtype=np.uint8)
         p.nearest_log, p.accept_log = r.nearest_log.ctypes.data, r.accept_log.ctypes.data
     status = _dub_lib().orc_dubins_plan(C.byref(p))
-    for k in ("j", "vgoal", "found", "rows", "sum_j", "sum_cells_nn", "sum_near", "sum_cells_cand", "n_dubins"):
+    for k in ("j", "vgoal", "found", "rows", "sum_j", "sum_cells_nn", "sum_near", "sum_cells_cand", "n_dubins",
+              "near_of_rejected", "lb_static_skip", "lb_evals", "lb_sweeps", "lb_violations", "lb_mismatch"):
         setattr(r, k, getattr(p, k))
     return status, r

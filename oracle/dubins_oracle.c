@@ -46,7 +46,19 @@ typedef struct {
     uint8_t *accept_log;     /* optional (n) */
     int32_t j, vgoal, found, rows;
     int64_t sum_j, sum_cells_nn, sum_near, sum_cells_cand, n_dubins; /* n_dubins: shortest-word evaluations */
+    /* ---- optional study of a pruned choose-parent search (counters != 0; costs time, changes no result) ----
+     * A Dubins word is never shorter than the chord between its end points, so vcost[v] + chord(v, x) bounds the cost through v
+     * from below.  DUB_LB_SLACK keeps the bound below the COMPUTED cost whatever the rounding of the word's arithmetic. */
+    int32_t counters, pad2_;
+    int64_t near_of_rejected;  /* near-set entries of samples that rrt.py:425 rejects (a kernel that prices before it knows) */
+    int64_t lb_static_skip;    /* entries whose bound is not below the cost through the nearest vertex */
+    int64_t lb_evals;          /* word evaluations of a search in (bound, index) order that stops at the first bound not below the best so far */
+    int64_t lb_sweeps;         /* sweeps of that search */
+    int64_t lb_violations;     /* evaluations with computed length below the slackened chord (must be 0) */
+    int64_t lb_mismatch;       /* accepted samples where that search ends at another (parent, cost) than the walk of rrt.py:515-521 (must be 0) */
 } orc_dub_t;
+
+#define DUB_LB_SLACK (1.0 - 1e-9)
 
 /* shortest word between two poses of the plan */
 static dub_path_t dub_between(const orc_dub_t *p, int32_t ax, int32_t ay, int32_t ah, int32_t bx, int32_t by, int32_t bh) {
@@ -76,6 +88,18 @@ typedef struct {
     double c;
     int32_t idx;
 } dub_ci;
+typedef struct {
+    double lb, cn;
+    int32_t idx, swept, free_;
+    dub_path_t path;
+} dub_lbe;
+static int dub_lbe_cmp(const void *a, const void *b) {
+    const dub_lbe *p = (const dub_lbe *)a, *q = (const dub_lbe *)b;
+    if (p->lb < q->lb) return -1;
+    if (p->lb > q->lb) return 1;
+    return (p->idx > q->idx) - (p->idx < q->idx);
+}
+
 static int dub_ci_cmp(const void *a, const void *b) {
     const dub_ci *p = (const dub_ci *)a, *q = (const dub_ci *)b;
     if (p->c < q->c) return -1;
@@ -99,6 +123,8 @@ int orc_dubins_plan(orc_dub_t *p) {
     uint8_t *sampled = (uint8_t *)calloc((size_t)W * H, 1);
     int32_t j = 1;
     p->sum_j = p->sum_cells_nn = p->sum_near = p->sum_cells_cand = p->n_dubins = 0;
+    p->near_of_rejected = p->lb_static_skip = p->lb_evals = p->lb_sweeps = p->lb_violations = p->lb_mismatch = 0;
+    dub_lbe *lbe = p->counters ? (dub_lbe *)malloc(sizeof(dub_lbe) * (size_t)(n + 1)) : NULL;
     for (int32_t i = 0; i < n; i++) { /* rrt.py:418 / :498 */
         const int32_t x = p->samples[2 * i], y = p->samples[2 * i + 1], h = p->headings[i];
         int64_t best = INT64_MAX;
@@ -120,10 +146,19 @@ int orc_dubins_plan(orc_dub_t *p) {
         const int acc = nocoll && !sampled[(size_t)x * H + y] && j != n; /* rrt.py:425, `sampled` keyed on the cell */
         if (p->nearest_log) p->nearest_log[i] = vnearest;
         if (p->accept_log) p->accept_log[i] = (uint8_t)acc;
-        if (!acc) continue;
+        if (!acc) {
+            if (p->counters && p->star)
+                for (int32_t vn = 0; vn < j; vn++) {
+                    const int64_t dx = (int64_t)p->pts[2 * vn] - x, dy = (int64_t)p->pts[2 * vn + 1] - y;
+                    if (dx * dx + dy * dy < p->r2_rewire) p->near_of_rejected++;
+                }
+            continue;
+        }
         sampled[(size_t)x * H + y] = 1;
         int32_t vbest = vnearest;
         double cbest = p->vcost[vnearest] + pn.len; /* rrt.py:512 */
+        const double c_nn = cbest;
+        int32_t nlbe = 0;
         if (p->star) {
             for (int32_t vn = 0; vn < j; vn++) { /* rrt.py:513-521: within() ascending, then the choose-parent walk */
                 const int64_t dx = (int64_t)p->pts[2 * vn] - x, dy = (int64_t)p->pts[2 * vn + 1] - y;
@@ -132,6 +167,16 @@ int orc_dubins_plan(orc_dub_t *p) {
                 dub_path_t pc = dub_between(p, p->pts[2 * vn], p->pts[2 * vn + 1], p->head[vn], x, y, h);
                 p->n_dubins++;
                 const double cn = p->vcost[vn] + pc.len;
+                if (p->counters) {
+                    const double chord = sqrt((double)(dx * dx + dy * dy));
+                    if (pc.len < chord * DUB_LB_SLACK) p->lb_violations++;
+                    lbe[nlbe].lb = p->vcost[vn] + chord * DUB_LB_SLACK;
+                    lbe[nlbe].cn = cn;
+                    lbe[nlbe].idx = vn;
+                    lbe[nlbe].swept = 0;
+                    lbe[nlbe].path = pc;
+                    nlbe++;
+                }
                 if (cn < cbest) {
                     int64_t cc = 0;
                     if (dub_sweep_free(p, p->pts[2 * vn], p->pts[2 * vn + 1], p->head[vn], x, y, &pc, &cc)) {
@@ -142,6 +187,25 @@ int orc_dubins_plan(orc_dub_t *p) {
                 }
             }
         }
+        if (p->counters && p->star) { /* the pruned search, on the side: must end where the walk above ended */
+            qsort(lbe, (size_t)nlbe, sizeof(dub_lbe), dub_lbe_cmp);
+            double cb = c_nn;
+            int32_t vb = -1; /* -1 = the nearest vertex, which wins every tie (strict < in rrt.py:518) */
+            for (int32_t e = 0; e < nlbe; e++) {
+                if (!(lbe[e].lb < c_nn)) p->lb_static_skip++;
+                if (!(lbe[e].lb < cb)) continue; /* (sorted: every later bound is not below cb either, counted on for the static figure) */
+                p->lb_evals++;
+                if (lbe[e].cn < cb || (lbe[e].cn == cb && vb >= 0 && lbe[e].idx < vb)) {
+                    int64_t cc = 0;
+                    p->lb_sweeps++;
+                    if (dub_sweep_free(p, p->pts[2 * lbe[e].idx], p->pts[2 * lbe[e].idx + 1], p->head[lbe[e].idx], x, y, &lbe[e].path, &cc)) {
+                        cb = lbe[e].cn;
+                        vb = lbe[e].idx;
+                    }
+                }
+            }
+            if ((vb < 0 ? vnearest : vb) != vbest || cb != cbest) p->lb_mismatch++;
+        }
         p->pts[2 * j] = x; /* rrt.py:524-529 */
         p->pts[2 * j + 1] = y;
         p->head[j] = h;
@@ -151,6 +215,7 @@ int orc_dubins_plan(orc_dub_t *p) {
     }
     p->j = j;
     free(sampled);
+    free(lbe);
     /* go2goal, rrt.py:311-332: cost to the goal pose for every node, stable (cost, index) order, first free sweep connects */
     dub_ci *cs = (dub_ci *)malloc(sizeof(dub_ci) * (size_t)j);
     for (int32_t k = 0; k < j; k++) {
