@@ -51,8 +51,9 @@ extern "C" {
 #define RRT_FLAG_REWIRE 32u /* opt-in TRUE RRT* rewire with cost propagation -- NOT the reference's behaviour: its
                               rewire step never fires (rrt.py:532-536 prices the rewire with vcosts[vn] + d, never below vcosts[vn]).
                               Semantics: oracle/rrt_oracle.c; runs on the one-sample-per-iteration kernel.  Default off. */
-#define RRT_FLAG_DUBINS 64u /* the batch runs Dubins queries (RRT_ALG_DUBINS / RRT_ALG_DUBINS_STAR) only: one-sample-per-iteration kernel
-                              with per-node headings.  rrt_plan sets it by itself for such a query. */
+#define RRT_FLAG_DUBINS 64u /* the batch runs Dubins queries (RRT_ALG_DUBINS / RRT_ALG_DUBINS_STAR) only, one CU per query: 16 samples per
+                              round on per-node headings and cell records (rrt_dubins_block.h); with RRT_FLAG_SERIAL the
+                              one-sample-per-iteration kernel, kept as a cross-check.  rrt_plan sets it by itself for such a query. */
 #define RRT_FLAG_TEAM_MAX(g) ((uint32_t)(g) << 8) /* cap the team size at g CUs per query (g = 2, 4, ... 64; 0 = no cap) */
 
 typedef struct rrt_ctx rrt_ctx;

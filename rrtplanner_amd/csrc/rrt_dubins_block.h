@@ -1,0 +1,499 @@
+// rrt_dubins_block.h -- Dubins-RRT / Dubins-RRT* (BASELINE.json configs[4]; no reference counterpart: include/rrt_dubins.h,
+// oracle/dubins_oracle.c) on one CU per query, 16 samples per round.
+//
+// The loop is the reference's (rrt.py:418-437 / :498-548) with the straight edge replaced by the shortest Dubins word: nearest
+// vertex on (x, y), sweep of the word nearest -> sample, accept test, choose parent over the radius ball, insert.  What is
+// expensive here is the word itself (~1150 dependent f64 operations), so the kernel is built around evaluating few of them:
+//
+//   rounds    the sample stream does not depend on the tree, so the 16 waves of the workgroup resolve 16 CONSECUTIVE samples
+//             side by side against the tree as it stands (one wave per sample), then wave 0 commits the longest prefix of them
+//             that no inserted sample of the same round can have influenced -- always at least one -- and the next round
+//             starts behind that prefix.  Results equal the sequential loop.
+//   nearest   every vertex also lives as a 16-byte record {xy, index, vcost} in the array of its cell of a uniform cell grid
+//             (the RRT* kernels' layout, rrt_block.h).  A wave streams the records of the cells its sample's radius ball touches
+//             as one packed stream; the nearest record of the box is near()[0] of the whole tree whenever it is no farther
+//             than the box radius (everything outside the box is), else the box is doubled.
+//   chord bound  a Dubins word is never shorter than the chord between its end points, so vcost[v] + |v - x| bounds the cost
+//             through v from below (oracle/dubins_oracle.c counts violations of the slackened bound in its study mode: none).
+//             The walk of rrt.py:515-521 ends at the (cost, index)-smallest visible entry below the cost through the nearest
+//             vertex; an entry whose bound is not below the best visible cost found so far can neither beat nor tie it (the
+//             bounds used are strictly below the computed costs), so it is never priced.  On BASELINE configs[4] 2.6 % of the
+//             near-set entries are priced (4 per accepted sample instead of 157).
+//   pass 1    the first stream leaves in every lane the entry with the smallest bound among the records that lane saw; those
+//             64 entries -- one of them replaced by the nearest vertex -- are priced in ONE word evaluation per lane, the
+//             nearest vertex's word is swept (accept test), and the priced entries below the cost through it are swept in
+//             (cost, index) order until one is visible.
+//   pass 2    only if some lane saw a second entry whose bound is below the best cost so far: the stream runs again, entries
+//             with a bound below the (tightening) best cost are collected in LDS and priced 64 at a time.
+#pragma once
+
+#include "rrt_kernels.h"
+
+namespace rrtdev {
+
+constexpr int DB_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
+
+// One sample as its wave resolved it against the tree of the round (64 bytes).
+struct DbRec {
+    uint32_t xq, hq;
+    uint32_t nn_idx, nn_d2;  // nearest vertex of the tree
+    uint32_t flags;          // bit 0: its word's sweep is free, bit 1: the sample's cell is already in `sampled`
+    uint32_t cells_nn;       // samples of that sweep read
+    uint32_t hits;           // |within| (RRT*)
+    uint32_t vb;             // parent
+    double cb;               // cost through the parent
+    uint32_t n_los, cells_cand, nwords, pad;
+    double pad2;
+};
+static_assert(sizeof(DbRec) == 64, "DbRec");
+
+struct DbLds {
+    alignas(16) uint32_t cellcnt[MAX_CELLS];  // live fill counts of the cells; go2goal's two 8 KiB tables afterwards
+    alignas(16) u32x4 buf[NWAVE][DB_BUF];     // pass 2: collected entries {xy, index, vcost}
+    alignas(16) DbRec rec[NWAVE];
+    alignas(16) BSlot bslots[2 * NWAVE];
+    int32_t st_i, st_j;
+};
+
+// conservative single-precision lower bound of vcost + chord (see the head comment): below the f64 value by more than every
+// rounding on the way, for costs up to ~1e5 cells
+__device__ __forceinline__ float db_lower_bound(double V, uint32_t d2) {
+    const float s = ((float)V + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
+    return s > 0.0f ? s : 0.0f;
+}
+
+__global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
+    __shared__ DbLds L;
+    const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int q = (int)blockIdx.x;
+    QDesc *D = bv.desc + q;
+    if (D->status != ST_RUNNING) return;
+
+    // ---- per-query views ----
+    const int n = D->n;
+    const bool star = D->alg == 4;
+    uint8_t *heading = bv.heading + (size_t)q * bv.node_stride;
+    const uint8_t *shead = bv.sample_heading + (size_t)q * bv.n_cap;
+    const DubCfg dc{D->rho, D->nh, bv.W, bv.H};
+    const uint32_t *samples = bv.samples + (size_t)q * bv.n_cap;
+    uint32_t *nodes_g = bv.nodes + (size_t)q * bv.node_stride;
+    double *vcost = bv.vcost + (size_t)q * bv.node_stride;
+    int32_t *parent = bv.parent + (size_t)q * bv.node_stride;
+    uint32_t *bitmap = bv.bitmap + (size_t)q * bv.bitmap_words;
+    uint2 *spill = bv.spill + (size_t)q * bv.spill_stride;
+    const bool logs = bv.nearest_log != nullptr;
+    const uint8_t *og = bv.og;
+    const int W = bv.W, H = bv.H;
+    const uint32_t r2 = D->r2_rewire;
+    const uint32_t xg = pack_xy(D->xg[0], D->xg[1]);
+    const int cshift = D->cell_shift, ncx = D->ncx, ncy = D->ncy, ccap = D->cell_cap, ncells = ncx * ncy;
+    u32x4 *cellrec = reinterpret_cast<u32x4 *>(bv.cellrec) + (size_t)q * (size_t)bv.rec_stride;
+    uint32_t *cellcnt_g = bv.cellcnt + (size_t)q * (size_t)MAX_CELLS;
+    RRT_LDS uint32_t *cellcnt = (RRT_LDS uint32_t *)L.cellcnt;
+    // radius of the first record stream: the rewire radius, but at least two cells (Dubins-RRT has no near set, and a tiny
+    // radius would leave the nearest-vertex search to the doubling below)
+    int rad0 = 0;
+    {
+        const uint32_t two = (uint32_t)((2 << cshift) * (2 << cshift));
+        const uint32_t rr = (star && r2 > two) ? r2 : two;
+        rad0 = (rr >= (1u << 23)) ? 4096 : (int)sqrtf((float)(rr - 1));
+        while (rad0 > 0 && (uint32_t)(rad0 * rad0) > rr - 1) --rad0;
+        while ((uint32_t)((rad0 + 1) * (rad0 + 1)) <= rr - 1) ++rad0;
+    }
+
+    int i = D->i, j = D->j;
+    unsigned long long sum_j = D->sum_j, sum_cells_nn = D->sum_cells_nn, sum_near = D->sum_near, sum_cells_cand = D->sum_cells_cand,
+                       n_los_cand = D->n_los_cand, n_words = D->n_words;
+#ifdef RRT_STAMPS
+    unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
+    unsigned long long tstamp = __builtin_amdgcn_s_memtime();
+#endif
+
+#ifdef RRT_STAMPS
+#define DSTAMP(k)                                               \
+    do {                                                        \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        cyc[k] += now_ - tstamp;                                \
+        tstamp = now_;                                          \
+    } while (0)
+#else
+#define DSTAMP(k) \
+    do {          \
+    } while (0)
+#endif
+    for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
+    __syncthreads();
+
+    const float FINF = __uint_as_float(0x7f800000u);
+    auto cell_of = [&](uint32_t X) -> int { return (ux(X) >> cshift) * ncy + (uy(X) >> cshift); };
+
+    // The records of the cells that the box of half-width `rad` around X touches, as ONE packed stream: lane l of a step takes
+    // record 64 * step + l of the concatenation of the cells' arrays (exclusive prefix sum of the fill counts over the lanes, the
+    // cell of a record by bisection over that prefix with ds_bpermute), 64 cells at a time.  f(record, live) once per step.
+    auto stream_box = [&](uint32_t X, int rad, auto &&f) {
+        const int x = ux(X), y = uy(X);
+        const int cx0 = (x - rad < 0 ? 0 : x - rad) >> cshift, cx1 = (x + rad > W - 1 ? W - 1 : x + rad) >> cshift;
+        const int cy0 = (y - rad < 0 ? 0 : y - rad) >> cshift, cy1 = (y + rad > H - 1 ? H - 1 : y + rad) >> cshift;
+        const int ny = cy1 - cy0 + 1, ncr = (cx1 - cx0 + 1) * ny;
+        for (int cbase = 0; cbase < ncr; cbase += 64) {
+            uint32_t tcnt = 0, toff = 0;
+            if (cbase + lane < ncr) {
+                const int ci = cbase + lane, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
+                tcnt = cellcnt[cell];
+                toff = (uint32_t)cell * (uint32_t)ccap;
+            }
+            uint32_t incl = tcnt;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t pre = incl - tcnt;  // lanes past the last cell hold `total`: never <= a live record number
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const uint32_t idx = base + (uint32_t)lane;
+                uint32_t lo = 0;  // the largest cell c with pre[c] <= idx
+#pragma unroll
+                for (uint32_t bit = 32; bit != 0; bit >>= 1) {
+                    const uint32_t cand = lo + bit;
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cand << 2), (int)pre);
+                    lo = v <= idx ? cand : lo;
+                }
+                const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
+                const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
+                const bool live = idx < total;
+                const u32x4 rc = cellrec[live ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
+                f(rc, live);
+            }
+        }
+    };
+
+    // a word (uniform after the call): the five values of lane `src`
+    auto bcast_path = [&](const dub_path_t &p, int src) -> dub_path_t {
+        dub_path_t o;
+        o.t = __shfl(p.t, src);
+        o.p = __shfl(p.p, src);
+        o.q = __shfl(p.q, src);
+        o.len = __shfl(p.len, src);
+        o.word = __shfl(p.word, src);
+        return o;
+    };
+
+    // Sweep the priced entries of this wave (lane: has, cost cn through vertex idx at a / ha by word pth) that can still become
+    // the parent, cheapest first, until one is visible (rrt.py:515-521 ends at the (cost, index)-smallest visible entry below the
+    // cost through the nearest vertex; `vb == NONE` while the nearest vertex, which wins every tie, is the parent).
+    auto test_priced = [&](bool has, double cn, uint32_t idx, uint32_t a, int ha, const dub_path_t &pth, uint32_t xq, double &cb, uint32_t &vb,
+                           uint32_t &nlos, uint32_t &ccells) {
+        bool open = has;
+        for (;;) {
+            const bool better = open && (cn < cb || (cn == cb && vb != NONE && idx < vb));
+            double c = better ? cn : f64_inf();
+            uint32_t ix = better ? idx : NONE;
+            wave_min_f64_idx(c, ix);
+            if (ix == NONE) break;
+            const unsigned long long m = __ballot(better && idx == ix);
+            const int src = (int)__builtin_ctzll(m);
+            const dub_path_t p = bcast_path(pth, src);
+            const uint32_t pa = (uint32_t)__shfl((int)a, src);
+            const int pha = __shfl(ha, src);
+            int cc = 0;
+            const bool ok = dub_sweep_wave(og, dc, pa, pha, xq, p, lane, cc);  // rrt.py:519
+            nlos += 1;
+            ccells += (uint32_t)cc;
+            if (ok) {
+                cb = c;
+                vb = ix;
+                break;  // every other open entry is not below this one
+            }
+            if (lane == src) open = false;
+        }
+    };
+
+    for (;;) {
+        if (i >= n) break;
+        const int nb = (n - i) < NWAVE ? (n - i) : NWAVE;  // samples of this round
+        // =============================== resolve: wave w takes sample i + w ===============================
+        if (wave < nb) {
+            const uint32_t xq = samples[i + wave];
+            const int hq = (int)shead[i + wave];
+            const uint32_t cell = (uint32_t)ux(xq) * (uint32_t)H + (uint32_t)uy(xq);
+            const uint32_t bm_word = bitmap[cell >> 5];
+            // ---- pass 1 of the record stream: nearest record of the box, |within|, per lane the entry with the smallest bound ----
+            uint32_t hits = 0;
+            uint32_t ld2 = NONE, lidx = NONE, lxy = 0, lvl = 0, lvh = 0;  // this lane's nearest record
+            float m1f = FINF, m2f = FINF;                                 // smallest / second smallest bound among this lane's hits
+            uint32_t m1idx = NONE, m1xy = 0, m1vl = 0, m1vh = 0;
+            stream_box(xq, rad0, [&](const u32x4 rc, bool live) {
+                const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
+                const bool nearer = d2 < ld2 || (d2 == ld2 && live && rc.y < lidx);
+                ld2 = nearer ? d2 : ld2;
+                lidx = nearer ? rc.y : lidx;
+                lxy = nearer ? rc.x : lxy;
+                lvl = nearer ? rc.z : lvl;
+                lvh = nearer ? rc.w : lvh;
+                if (!star) return;
+                const bool hit = d2 < r2;  // within(), rrt.py:176-181 (d2 == NONE for a dead lane: never below r2 <= 2^24)
+                hits += hit ? 1u : 0u;
+                const double V = __longlong_as_double((long long)(((unsigned long long)rc.w << 32) | rc.z));
+                const float lb = hit ? db_lower_bound(V, d2) : FINF;
+                const bool first = lb < m1f || (lb == m1f && hit && rc.y < m1idx);
+                m2f = first ? m1f : __builtin_fminf(m2f, lb);
+                m1f = first ? lb : m1f;
+                m1idx = first ? rc.y : m1idx;
+                m1xy = first ? rc.x : m1xy;
+                m1vl = first ? rc.z : m1vl;
+                m1vh = first ? rc.w : m1vh;
+            });
+            uint32_t nn_d2 = ld2, nn_idx = lidx;
+            wave_min_key_idx(nn_d2, nn_idx);
+            int radn = rad0;
+            // nothing in the box, or something that a vertex outside the box could beat: double the box (nearest only)
+            while ((nn_d2 == NONE || nn_d2 > (uint32_t)radn * (uint32_t)radn) && radn < (W > H ? W : H)) {
+                radn = 2 * radn + 1;
+                ld2 = NONE;
+                lidx = NONE;
+                stream_box(xq, radn, [&](const u32x4 rc, bool live) {
+                    const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
+                    const bool nearer = d2 < ld2 || (d2 == ld2 && live && rc.y < lidx);
+                    ld2 = nearer ? d2 : ld2;
+                    lidx = nearer ? rc.y : lidx;
+                    lxy = nearer ? rc.x : lxy;
+                    lvl = nearer ? rc.z : lvl;
+                    lvh = nearer ? rc.w : lvh;
+                });
+                nn_d2 = ld2;
+                nn_idx = lidx;
+                wave_min_key_idx(nn_d2, nn_idx);
+            }
+            // the nearest vertex's record, uniform
+            uint32_t nn_xy, nn_vl, nn_vh;
+            {
+                const unsigned long long m = __ballot(lidx == nn_idx && ld2 == nn_d2);
+                const int src = (int)__builtin_ctzll(m);
+                nn_xy = (uint32_t)__shfl((int)lxy, src);
+                nn_vl = (uint32_t)__shfl((int)lvl, src);
+                nn_vh = (uint32_t)__shfl((int)lvh, src);
+            }
+            const uint32_t nhits = star ? wave_sum_u32(hits) : 0u;
+            DSTAMP(0);  // (diagnostic build, wave 0) the first record stream
+            // ---- the lane that prices the nearest vertex: the one whose own entry it is, else one without an entry, else the one
+            //      whose entry has the largest bound (that entry is left to pass 2) ----
+            int slot;
+            {
+                const unsigned long long own = __ballot(m1idx == nn_idx);
+                const unsigned long long none = __ballot(m1idx == NONE);
+                if (own) slot = (int)__builtin_ctzll(own);
+                else if (none) slot = (int)__builtin_ctzll(none);
+                else {
+                    const uint32_t inv = ~__float_as_uint(m1f);  // bounds are non-negative floats: the largest has the smallest complement
+                    const uint32_t mx = wave_min_u32(inv);
+                    slot = (int)__builtin_ctzll(__ballot(inv == mx));
+                }
+            }
+            float left = m2f;  // this lane's smallest bound among the entries it saw but does not price in pass 1
+            if (lane == slot && m1idx != nn_idx && m1idx != NONE) left = __builtin_fminf(left, m1f);
+            uint32_t e_idx = (lane == slot) ? nn_idx : m1idx;  // the vertex this lane prices (NONE: none)
+            const uint32_t e_xy = (lane == slot) ? nn_xy : m1xy;
+            const double e_V = __longlong_as_double((long long)(((unsigned long long)((lane == slot) ? nn_vh : m1vh) << 32) | ((lane == slot) ? nn_vl : m1vl)));
+            // ---- one word per lane ----
+            int e_h = 0;
+            dub_path_t e_p;
+            e_p.t = e_p.p = e_p.q = 0.0;
+            e_p.len = f64_inf();
+            e_p.word = DUB_NONE;
+            double e_cn = f64_inf();
+            if (e_idx != NONE) {
+                e_h = (int)heading[e_idx];
+                e_p = dub_between_dev(e_xy, e_h, xq, hq, dc);
+                e_cn = e_V + e_p.len;
+            }
+            uint32_t nwords = (uint32_t)__builtin_popcountll(__ballot(e_idx != NONE));
+            DSTAMP(1);  // one word per lane
+            // ---- nearest vertex: cost through it, its sweep (rrt.py:422-425) ----
+            const dub_path_t p_nn = bcast_path(e_p, slot);
+            const int h_nn = __shfl(e_h, slot);
+            const double c_nn = __shfl(e_cn, slot);
+            int cells = 0;
+            const bool nocoll = dub_sweep_wave(og, dc, nn_xy, h_nn, xq, p_nn, lane, cells);
+            const bool dup = ((bm_word >> (cell & 31)) & 1u) != 0u;
+            double cb = c_nn;
+            uint32_t vb = NONE, nlos = 0, ccells = 0;
+            if (star && nocoll && !dup) {
+                // ---- choose parent: the priced entries, then whatever pass 1 left unpriced below the best cost so far ----
+                test_priced(e_idx != NONE && lane != slot, e_cn, e_idx, e_xy, e_h, e_p, xq, cb, vb, nlos, ccells);
+                DSTAMP(2);  // the nearest vertex's sweep, the sweeps of the priced entries
+                if (__ballot((double)left < cb) != 0ull) {
+                    RRT_LDS u32x4 *buf = (RRT_LDS u32x4 *)L.buf[wave];
+                    uint32_t nbuf = 0;
+                    const uint32_t skip = (lane == slot) ? NONE : m1idx;  // this lane's entry of pass 1 (the stream deals the same records to the same lanes)
+                    auto flush = [&]() {
+                        u32x4 e = {0u, NONE, 0u, 0u};
+                        if ((uint32_t)lane < nbuf) e = buf[lane];
+                        const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                        bool has = e.y != NONE && (double)db_lower_bound(V, dist2(e.x, xq)) < cb;  // (the best cost may have fallen since the entry was collected)
+                        int fh = 0;
+                        dub_path_t fp;
+                        fp.t = fp.p = fp.q = 0.0;
+                        fp.len = f64_inf();
+                        fp.word = DUB_NONE;
+                        double fcn = f64_inf();
+                        if (has) {
+                            fh = (int)heading[e.y];
+                            fp = dub_between_dev(e.x, fh, xq, hq, dc);
+                            fcn = V + fp.len;
+                        }
+                        nwords += (uint32_t)__builtin_popcountll(__ballot(has));
+                        test_priced(has, fcn, e.y, e.x, fh, fp, xq, cb, vb, nlos, ccells);
+                        // drop the 64 entries just handled
+                        u32x4 mv = {0u, NONE, 0u, 0u};
+                        const bool tail = (uint32_t)lane + 64u < nbuf;
+                        if (tail) mv = buf[lane + 64];
+                        if (tail) buf[lane] = mv;
+                        nbuf = nbuf > 64u ? nbuf - 64u : 0u;
+                    };
+                    stream_box(xq, rad0, [&](const u32x4 rc, bool live) {
+                        const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
+                        const double V = __longlong_as_double((long long)(((unsigned long long)rc.w << 32) | rc.z));
+                        const bool take = d2 < r2 && rc.y != nn_idx && rc.y != skip && (double)db_lower_bound(V, d2) < cb;
+                        const unsigned long long tm = __ballot(take);
+                        if (tm == 0ull) return;
+                        if (take) buf[nbuf + (uint32_t)__builtin_popcountll(tm & ((1ull << lane) - 1ull))] = rc;
+                        nbuf += (uint32_t)__builtin_popcountll(tm);
+                        if (nbuf >= 64u) flush();
+                    });
+                    while (nbuf > 0u) flush();
+                    DSTAMP(3);  // pass 2: second stream, its word evaluations and sweeps
+                }
+            }
+            DSTAMP(2);
+            if (lane == 0) {
+                DbRec r;
+                r.xq = xq;
+                r.hq = (uint32_t)hq;
+                r.nn_idx = nn_idx;
+                r.nn_d2 = nn_d2;
+                r.flags = (nocoll ? 1u : 0u) | (dup ? 2u : 0u);
+                r.cells_nn = (uint32_t)cells;
+                r.hits = nhits;
+                r.vb = vb == NONE ? nn_idx : vb;
+                r.cb = cb;
+                r.n_los = nlos;
+                r.cells_cand = ccells;
+                r.nwords = nwords;
+                r.pad = 0;
+                r.pad2 = 0.0;
+                L.rec[wave] = r;
+            }
+        }
+        __syncthreads();
+        DSTAMP(4);  // wave 0's wait for the slowest wave of the round
+        // =============================== commit: wave 0, the longest prefix no inserted sample of the round touches ===============================
+        if (wave == 0) {
+            unsigned long long ins = 0;  // samples of this round inserted so far
+            uint32_t my_xq = 0;
+            double my_cost = 0.0;        // lane m: the cost of sample m once it is inserted
+            if (lane < nb) my_xq = L.rec[lane].xq;
+            int k = 0;
+            for (; k < nb; ++k) {
+                const DbRec r = L.rec[k];
+                const bool mine = lane < k && ((ins >> lane) & 1ull);
+                const uint32_t d2mk = dist2(my_xq, r.xq);
+                const bool pre_ok = (r.flags & 3u) == 1u;  // visible from the nearest vertex and not sampled before
+                const unsigned long long nearer = __ballot(mine && d2mk < r.nn_d2);  // (a new vertex loses ties: higher index)
+                const unsigned long long same = __ballot(mine && my_xq == r.xq);
+                const unsigned long long within = __ballot(mine && star && d2mk < r2);
+                // an inserted sample inside the ball is a candidate parent unless its chord bound is not below the chosen cost
+                const unsigned long long cand =
+                    __ballot(mine && star && d2mk < r2 && my_cost + sqrt_u32(d2mk) * (1.0 - 1.0e-9) < r.cb);
+                if (nearer != 0ull || (pre_ok && same == 0ull && cand != 0ull)) break;  // resolved again next round, against the tree with them in
+                const bool acc = pre_ok && same == 0ull && j != n;  // rrt.py:425
+                sum_j += (unsigned long long)j;
+                sum_cells_nn += (unsigned long long)r.cells_nn;
+                n_words += (unsigned long long)r.nwords;
+                if (logs && lane == 0) {
+                    bv.nearest_log[(size_t)q * bv.n_cap + i + k] = (int32_t)r.nn_idx;
+                    bv.accept_log[(size_t)q * bv.n_cap + i + k] = (uint8_t)acc;
+                    bv.cbest_log[(size_t)q * bv.n_cap + i + k] = __longlong_as_double(0x7ff8000000000000ll);
+                    bv.j_log[(size_t)q * bv.n_cap + i + k] = j;
+                }
+                if (!acc) continue;
+                if (star) {
+                    sum_near += (unsigned long long)r.hits + (unsigned long long)__builtin_popcountll(within);
+                    n_los_cand += (unsigned long long)r.n_los;
+                    sum_cells_cand += (unsigned long long)r.cells_cand;
+                }
+                if (lane == 0) {  // rrt.py:524-529
+                    nodes_g[j] = r.xq;
+                    heading[j] = (uint8_t)r.hq;
+                    vcost[j] = r.cb;
+                    parent[j] = (int32_t)r.vb;
+                    const uint32_t cellb = (uint32_t)ux(r.xq) * (uint32_t)H + (uint32_t)uy(r.xq);
+                    atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
+                    const int c = cell_of(r.xq);
+                    const uint32_t pos = cellcnt[c];
+                    const unsigned long long cbits = (unsigned long long)__double_as_longlong(r.cb);
+                    cellrec[(size_t)c * (size_t)ccap + pos] = u32x4{r.xq, (uint32_t)j, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+                    cellcnt[c] = pos + 1;
+                }
+                if (lane == k) my_cost = r.cb;
+                ins |= 1ull << k;
+                j++;
+            }
+            i += k;  // k >= 1: sample 0 of a round has no earlier sample
+            if (lane == 0) {
+                L.st_i = i;
+                L.st_j = j;
+            }
+        }
+        __syncthreads();  // the inserted vertices, their records and the fill counts are visible to every wave
+        i = L.st_i;
+        j = L.st_j;
+        DSTAMP(5);  // commit + publication
+    }
+
+    for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
+    __syncthreads();
+
+    // ---------------- go2goal (rrt.py:311-332) ----------------
+    int status = ST_DONE, vgoal = 0, found = 0;
+    {
+        double pc;
+        uint32_t pi;
+        go2goal_phase<true>(og, H, nodes_g, vcost, 0, 1, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)L.cellcnt, L.bslots, t, lane, wave, pc, pi,
+                            heading, D->hg, dc);
+        if (pi != NONE) {
+            found = 1;
+            vgoal = j;
+            if (t == 0) {
+                nodes_g[j] = xg;
+                vcost[j] = pc;
+                parent[j] = (int32_t)pi;
+                heading[j] = (uint8_t)D->hg;
+            }
+        } else {
+            if (j < n) status = ST_UNREACHABLE;
+            vgoal = 0;
+        }
+    }
+    if (t == 0) {
+        D->status = status;
+        D->i = i;
+        D->j = j;
+        D->vgoal = vgoal;
+        D->found = found;
+        D->sum_j = sum_j;
+        D->sum_cells_nn = sum_cells_nn;
+        D->sum_near = sum_near;
+        D->sum_cells_cand = sum_cells_cand;
+        D->n_los_cand = n_los_cand;
+        D->n_words = n_words;
+#ifdef RRT_STAMPS
+        for (int k = 0; k < 6; ++k) D->cyc[k] = cyc[k];
+#endif
+    }
+}
+
+#undef DSTAMP
+
+}  // namespace rrtdev

@@ -18,6 +18,7 @@
 #include "rrt_hip.h"
 #include "rrt_kernels.h"
 #include "rrt_block.h"
+#include "rrt_dubins_block.h"
 #include "rrt_prims.h"
 
 using namespace rrtdev;
@@ -80,6 +81,7 @@ struct rrt_batch {
     int32_t gridW = 0, gridH = 0;
     uint32_t flags = 0;
     bool use_block = false;     // block-parallel kernel (rrt_block.h) instead of the one-sample-per-iteration kernel
+    bool dub_block = false;     // Dubins planners on the 16-samples-per-round kernel (rrt_dubins_block.h); RRT_FLAG_SERIAL keeps the one-sample kernel
     int32_t blk_lds_chunks = 1; // node chunks cached in LDS by the block kernel: teams of 8 and more workers ...
     int32_t blk_lds_chunks16 = 1; // ... and the kernels that also keep their parked-entry lists there
     int32_t team = 1;           // workgroups (CUs) per query of the block kernel that scan and resolve (rrt_block.h, teams)
@@ -453,6 +455,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     }
     // the opt-in rewire and the Dubins planners run on the one-sample-per-iteration kernel
     b->use_block = !(flags & (RRT_FLAG_SERIAL | RRT_FLAG_REWIRE | RRT_FLAG_DUBINS));
+    b->dub_block = (flags & RRT_FLAG_DUBINS) && !(flags & RRT_FLAG_SERIAL);
     if (b->use_block && !(flags & RRT_FLAG_NOTEAM)) {
         // the largest team (CUs per query) with every member of every team resident at once.  Blocks are dealt round-robin
         // to the 8 XCDs, so block = member * stride + query with stride = 0 (mod 8) keeps a team of up to 16 on one XCD (one
@@ -493,6 +496,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
         // single CUs, where one wave resolves a sample: rrt_block.h LDSLIST)]
         const size_t budget = (size_t)ctx->max_lds - block_kernel_static_lds(b->team);
         const size_t fixed = (size_t)MAX_CELLS * sizeof(uint32_t);
+        if (b->dub_block) b->rec_stride = cell_records_needed(ctx->W, ctx->H, n_cap);
         if (b->use_block) {
             int nc = (int)((budget - fixed) / ((size_t)CHUNK * sizeof(uint32_t)));
             b->blk_lds_chunks = nc > chunks ? chunks : nc;
@@ -527,10 +531,10 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->d_parent = reinterpret_cast<int32_t *>(b->d_slab + q * b->node_stride * (sizeof(double) + sizeof(uint32_t)));
     ALLOC(b->d_bitmap, q * b->bitmap_words * sizeof(uint32_t));
     ALLOC(b->d_spill, q * b->spill_stride * sizeof(uint2));
-    if (b->use_block) {
+    if (b->use_block || b->dub_block) {
         ALLOC(b->d_cellrec, q * (size_t)b->rec_stride * sizeof(uint4));
         ALLOC(b->d_cellcnt, q * (size_t)MAX_CELLS * sizeof(uint32_t));
-        if (b->team > 1) ALLOC(b->d_team, q * (size_t)TEAM_BYTES);
+        if (b->use_block && b->team > 1) ALLOC(b->d_team, q * (size_t)TEAM_BYTES);
     }
     if (flags & RRT_FLAG_REWIRE) {
         ALLOC(b->d_kids, 3 * q * b->node_stride * sizeof(int32_t));
@@ -540,7 +544,7 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     if (flags & RRT_FLAG_DUBINS) {
         ALLOC(b->d_heading, q * b->node_stride);
         ALLOC(b->d_shead, q * n_cap);
-        ALLOC(b->d_dubpath, q * (size_t)(NWAVE * WCAP) * 5 * sizeof(double));
+        if (!b->dub_block) ALLOC(b->d_dubpath, q * (size_t)(NWAVE * WCAP) * 5 * sizeof(double));
     }
     if (flags & RRT_FLAG_LOGS) {
         ALLOC(b->d_nearest_log, q * n_cap * sizeof(int32_t));
@@ -812,6 +816,15 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         b->timed = true;
         return RRT_OK;
     }
+    if (b->dub_block) {
+        hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+        HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
+        hipLaunchKernelGGL(rrt_dubins_block_kernel, dim3((unsigned)b->Q), dim3(TPB), 0, ctx->stream, v);
+        HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        b->timed = true;
+        return RRT_OK;
+    }
     const size_t lds = expand_lds_bytes(b->lds_chunks);
     typedef void (*serial_kernel_fn)(BatchView);
     const serial_kernel_fn kern = (b->flags & RRT_FLAG_DUBINS)  ? static_cast<serial_kernel_fn>(rrt_expand_kernel<false, true>)
@@ -883,6 +896,8 @@ extern "C" int rrt_batch_kernel_name(rrt_batch *b, char *buf, int32_t len) {
         const int team = b->last_team > 0 ? b->last_team : b->team;
         const int bsm = team <= 4 ? 16 : 64 / team;
         snprintf(tmp, sizeof tmp, "rrt_expand_block_kernel<%d, %d, %s, %s>", team, bsm, (team > 1 && b->pipe) ? "true" : "false", b->last_inf ? "true" : "false");
+    } else if (b->dub_block) {
+        snprintf(tmp, sizeof tmp, "rrt_dubins_block_kernel");
     } else {
         snprintf(tmp, sizeof tmp, "rrt_expand_kernel<%s, %s>", (b->flags & RRT_FLAG_REWIRE) ? "true" : "false", (b->flags & RRT_FLAG_DUBINS) ? "true" : "false");
     }

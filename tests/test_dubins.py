@@ -100,6 +100,46 @@ def _dub_query(grid, n, seed, gseed=1):
     return og, og8, (int(xs[0]), int(xs[1]), 5), (int(xg[0]), int(xg[1]), 20), samples, heads
 
 
+def _independent_sweep(og8, a, b, rho, nh):
+    """The collision sweep of the edge a -> b WITHOUT include/rrt_dubins.h: the polyline of rrtplanner_amd/dubins.py (numpy /
+    libm, its own word construction) sampled every DUB_DS = 0.5 cells of arc length, a sample occupying the cell round-half-up
+    of its coordinates.  Returns (blocked, ambiguous) per sample: blocked = outside the grid or on an obstacle; ambiguous = a
+    coordinate within 1e-7 of a cell boundary (libm and the fixed-order arithmetic may then name neighbouring cells)."""
+    f = dub.dubins_polyline(a, b, rho, nh, ds=0.5) + 0.5
+    cells = np.floor(f).astype(np.int64)
+    amb = np.abs(f - np.round(f)).min(axis=1) < 1e-7
+    inside = (cells[:, 0] >= 0) & (cells[:, 0] < og8.shape[0]) & (cells[:, 1] >= 0) & (cells[:, 1] < og8.shape[1])
+    blocked = ~inside
+    blocked[inside] = og8[cells[inside, 0], cells[inside, 1]] != 0
+    return blocked, amb
+
+
+def _independent_collision_witness(og8, res, samples, heads, rho, nh, count=300):
+    """The device's collision DECISIONS against the independent sweep above (the oracle shares the kernel's geometry header, so
+    HIP == oracle says nothing about a wrong formula in it): every edge of the device's tree is free, and every iteration the
+    device rejected although its cell was new has a blocked (or boundary-ambiguous) sample on the word nearest -> sample."""
+    live = res.j + (1 if res.found else 0)
+    par, pts, hd = res.parent[:live].astype(np.int64), res.pts[:live].astype(np.int64), res.head[:live].astype(np.int64)
+    for c in range(1, live, max(1, live // count)):
+        p = par[c]
+        blocked, amb = _independent_sweep(og8, (pts[p, 0], pts[p, 1], hd[p]), (pts[c, 0], pts[c, 1], hd[c]), rho, nh)
+        assert not np.any(blocked & ~amb), f"edge {p} -> {c} of the device's tree crosses an obstacle"
+    first_index = {}
+    for k in range(res.j - 1, 0, -1):
+        first_index[(int(pts[k, 0]), int(pts[k, 1]))] = k
+    rej = np.flatnonzero(res.accept_log == 0)
+    seen = 0
+    for i in rej[:: max(1, rej.size // count)]:
+        x, y, h, jtop = int(samples[i, 0]), int(samples[i, 1]), int(heads[i]), int(res.j_log[i])
+        if first_index.get((x, y), jtop) < jtop or jtop >= res.n:
+            continue  # rejected as a duplicate of an earlier vertex (rrt.py:425) or because the tree is full
+        v = int(res.nearest_log[i])
+        blocked, amb = _independent_sweep(og8, (pts[v, 0], pts[v, 1], hd[v]), (x, y, h), rho, nh)
+        assert np.any(blocked | amb), f"iteration {i}: rejected, but the word from vertex {v} to the sample is free"
+        seen += 1
+    return seen
+
+
 def _check_dubins_tree(og8, r, rho, nh, xs):
     live = r.j + (1 if r.found else 0)
     par, pts, hd = r.parent[:live].astype(np.int64), r.pts[:live].astype(np.int64), r.head[:live].astype(np.int64)
@@ -155,11 +195,13 @@ def test_planner_classes_on_the_oracle_stand_in():
 
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
-def _device_vs_oracle_dubins(ctx, og8, star, n, xs, xg, samples, heads, rr, rho, nh=64):
+def _device_vs_oracle_dubins(ctx, og8, star, n, xs, xg, samples, heads, rr, rho, nh=64, serial=False, counters=False):
+    """serial = False: the 16-samples-per-round kernel (rrt_dubins_block.h, the default); True: the one-sample-per-iteration
+    kernel (RRT_FLAG_SERIAL), kept as a second implementation of the same semantics."""
     r2 = hostprep.radius_threshold(rr) if star else 0
     q, keep = _ffi.make_query(_ffi.ALG_DUBINS_STAR if star else _ffi.ALG_DUBINS, n, xs, xg, samples, r2_rewire=r2, headings=heads, rho=rho, nh=nh)
-    rc, res = ctx.plan(q, n, logs=True)
-    st, ro = oracle.dubins_plan(og8, n, star, xs, xg, samples, heads, r2_rewire=r2, rho=rho, nh=nh)
+    rc, res = ctx.plan(q, n, logs=True, serial=serial)
+    st, ro = oracle.dubins_plan(og8, n, star, xs, xg, samples, heads, r2_rewire=r2, rho=rho, nh=nh, counters=counters)
     assert rc == st
     live = ro.j + (1 if ro.found else 0)
     assert (res.j, res.found, res.vgoal) == (ro.j, ro.found, ro.vgoal)
@@ -175,11 +217,44 @@ def _device_vs_oracle_dubins(ctx, og8, star, n, xs, xg, samples, heads, rr, rho,
 @pytest.mark.parametrize("star,grid,n,rr,rho,seed", [
     (0, 300, 4000, None, 6.0, 0), (1, 300, 4000, 40, 6.0, 0), (1, 1024, 20000, 64, 8.0, 1), (1, 64, 2500, 12, 2.0, 2),
     (1, 200, 3000, 1e6, 4.0, 3), (0, 2048, 30000, None, 8.0, 5), (1, 2048, 30000, 64, 8.0, 5), (1, 128, 1500, 20, 25.0, 6)])
-def test_device_dubins_equals_the_oracle(gpu_ctx, star, grid, n, rr, rho, seed):
+@pytest.mark.parametrize("serial", [False, True])
+def test_device_dubins_equals_the_oracle(gpu_ctx, star, grid, n, rr, rho, seed, serial):
     og, og8, xs, xg, samples, heads = _dub_query(grid, n, seed, gseed=3 if grid == 2048 else 1)
     gpu_ctx.set_grid(og8)
-    res, ro = _device_vs_oracle_dubins(gpu_ctx, og8, star, n, xs, xg, samples, heads, rr, rho)
+    res, ro = _device_vs_oracle_dubins(gpu_ctx, og8, star, n, xs, xg, samples, heads, rr, rho, serial=serial)
     _check_dubins_tree(og8, res, rho, 64, xs)
+    if not serial:
+        _independent_collision_witness(og8, res, samples, heads, rho, 64)
+    assert res.n_words > 0 or serial  # (the one-sample-per-iteration kernel does not count its words)
+
+
+@pytest.mark.gpu
+def test_config5_full_size_equals_the_oracle(gpu_ctx):
+    """BASELINE configs[4] at its own size -- Dubins-RRT*, 2048 x 2048, n = 100000, r_rewire = 64, rho = 8, 64 headings --
+    exactly as `bench.py --config 5` poses query 0: the whole tree (vertices, headings, parents, costs bit for bit, per-iteration
+    nearest / accept logs, statistics) equals the oracle's.  The oracle runs in its study mode next to it: no word it evaluates
+    is shorter than the slackened chord the kernel prunes with, and a search pruned by that bound ends at the parent the
+    index-order walk of rrt.py:515-521 chooses, for every accepted sample."""
+    import bench
+
+    cfg = bench.CONFIGS[5]
+    n = cfg["n"]
+    og = perlin_occupancygrid(cfg["grid"], cfg["grid"], thresh=0.33, seed=cfg["grid_seed"])
+    og8 = oracle.og_u8(og)
+    free = np.argwhere(og == 0)
+    from rrtplanner_amd.oggen import random_connected_pairs
+
+    a, b = random_connected_pairs(og, np.random.default_rng(7), 1)[0]
+    rng = np.random.default_rng(0)
+    samples = hostprep.draw_free_samples(rng, free, n)
+    heads = rng.integers(0, cfg["nh"], size=n)
+    xs, xg = (int(a[0]), int(a[1]), 0), (int(b[0]), int(b[1]), 5 % cfg["nh"])
+    gpu_ctx.set_grid(og8)
+    res, ro = _device_vs_oracle_dubins(gpu_ctx, og8, 1, n, xs, xg, samples, heads, cfg["r_rewire"], cfg["rho"], cfg["nh"], counters=True)
+    assert ro.j > 80000 and ro.lb_violations == 0 and ro.lb_mismatch == 0
+    assert 0 < res.n_words < ro.n_dubins // 2  # the oracle's walk prices every near-set entry; the kernel one per lane of a pass, up to 64
+    _check_dubins_tree(og8, res, cfg["rho"], cfg["nh"], xs)
+    assert _independent_collision_witness(og8, res, samples, heads, cfg["rho"], cfg["nh"], count=400) > 50
 
 
 @pytest.mark.gpu
@@ -203,7 +278,7 @@ def test_device_dubins_fuzz_small(gpu_ctx):
         heads = srng.integers(0, nh, size=n)
         gpu_ctx.set_grid(og8)
         try:
-            _device_vs_oracle_dubins(gpu_ctx, og8, star, n, xs, xg, samples, heads, rr, rho, nh)
+            _device_vs_oracle_dubins(gpu_ctx, og8, star, n, xs, xg, samples, heads, rr, rho, nh, serial=bool(case % 3 == 2))
         except AssertionError as e:
             raise AssertionError(f"dubins fuzz case {case}: {w}x{h} star {star} n {n} nh {nh} rho {rho} r {rr} xs {xs} xg {xg}") from e
 

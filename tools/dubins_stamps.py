@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase shader cycles of the Dubins kernel (rrt_expand_kernel<false, true>, wave 0 of one query) from the stamped build.
+"""Diagnostic: per-phase shader cycles of the Dubins kernels (wave 0 of one query) from the stamped build.
 
     make -C rrtplanner_amd/csrc ../librrt_hip_stamps.so
-    RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so python tools/dubins_stamps.py
+    RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so python tools/dubins_stamps.py [serial]
+
+Default: rrt_dubins_block_kernel (16 samples per round); `serial`: rrt_expand_kernel<false, true>.
 
 BASELINE config 5's shape (2048 x 2048, n = 100 000, r_rewire = 64, rho = 8, 64 headings), one query.  Never quote the stamped
 build's run time; read the shares."""
@@ -20,7 +22,8 @@ rng = np.random.default_rng(3)
 samples = hostprep.draw_free_samples(rng, np.argwhere(og8 == 0), n)
 heads = rng.integers(0, 64, size=n)
 ctx = _ffi.Context(0); ctx.set_grid(og8)
-b = _ffi.Batch(ctx, 1, n, dubins=True)
+serial = len(sys.argv) > 1 and sys.argv[1] == 'serial'
+b = _ffi.Batch(ctx, 1, n, dubins=True, serial=serial)
 q, keep = _ffi.make_query(_ffi.ALG_DUBINS_STAR, n, (int(xs[0]), int(xs[1]), 5), (int(xg[0]), int(xg[1]), 20), samples, r2_rewire=hostprep.radius_threshold(64), headings=heads, rho=8.0, nh=64)
 b.set_query(0, q)
 for rep in range(2):
@@ -29,7 +32,9 @@ ms = b.elapsed_ms()
 r = b.get_result(0, arrays=False)
 cyc = b.debug_cycles(0)
 print("kernel %.1f ms, j=%d, %.0f cyc/iter (at 2.4 GHz)" % (ms, r.c.j, ms * 2.4e6 / n))
-names = ["A scan", "pricing (wave 0's entries)", "wait for the nearest's word + sweep", "acceptance, test rounds", "D insert", "go2goal"]
+print("kernel:", b.kernel_name(), " word evaluations per iteration: %.2f" % (r.c.n_words / n))
+names = (["A scan", "pricing (wave 0's entries)", "wait for the nearest's word + sweep", "acceptance, test rounds", "D insert", "go2goal"] if serial else
+         ["first record stream", "one word per lane", "sweeps (nearest + priced entries)", "pass 2 (stream, words, sweeps)", "wait for the slowest wave", "commit + publication"])
 tot = sum(cyc[:6]) or 1
 for nm, c in zip(names, cyc[:6]): print("  %-32s %12d  %5.1f%%  %8.1f cyc/iter" % (nm, c, 100 * c / tot, c / n))
 print("near", r.c.sum_near / n, "los_cand", r.c.n_los_cand / n)
