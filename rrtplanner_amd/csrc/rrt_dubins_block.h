@@ -53,6 +53,7 @@ struct DbLds {
     alignas(16) DbRec rec[NWAVE];
     alignas(16) BSlot bslots[2 * NWAVE];
     int32_t st_i, st_j;
+    unsigned long long stat[6][NWAVE];
 };
 
 // conservative single-precision lower bound of vcost + chord (see the head comment): below the f64 value by more than every
@@ -102,8 +103,8 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     }
 
     int i = D->i, j = D->j;
-    unsigned long long sum_j = D->sum_j, sum_cells_nn = D->sum_cells_nn, sum_near = D->sum_near, sum_cells_cand = D->sum_cells_cand,
-                       n_los_cand = D->n_los_cand, n_words = D->n_words;
+    // statistics: per-lane sums of wave 0 in LDS (lane k: the samples it committed), folded once at the end
+    if (t < 6 * NWAVE) (&L.stat[0][0])[t] = 0ull;
 #ifdef RRT_STAMPS
     unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
@@ -388,59 +389,71 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
         }
         __syncthreads();
         DSTAMP(4);  // wave 0's wait for the slowest wave of the round
-        // =============================== commit: wave 0, the longest prefix no inserted sample of the round touches ===============================
+        // =============================== commit: wave 0, one lane per sample ===============================
+        // The longest prefix of the round that no inserted sample of the same round can have influenced.  Sample k is touched by an
+        // earlier INSERTED sample m when m is nearer than k's nearest vertex (a new vertex loses ties: higher index), or -- k
+        // visible and on a new cell -- when m lies in k's ball with a chord bound below k's chosen cost.  Which samples are
+        // inserted is known up front: the first visible sample on a cell (rrt.py:425), while the tree is not full.
         if (wave == 0) {
-            unsigned long long ins = 0;  // samples of this round inserted so far
-            uint32_t my_xq = 0;
-            double my_cost = 0.0;        // lane m: the cost of sample m once it is inserted
-            if (lane < nb) my_xq = L.rec[lane].xq;
-            int k = 0;
-            for (; k < nb; ++k) {
-                const DbRec r = L.rec[k];
-                const bool mine = lane < k && ((ins >> lane) & 1ull);
-                const uint32_t d2mk = dist2(my_xq, r.xq);
-                const bool pre_ok = (r.flags & 3u) == 1u;  // visible from the nearest vertex and not sampled before
-                const unsigned long long nearer = __ballot(mine && d2mk < r.nn_d2);  // (a new vertex loses ties: higher index)
-                const unsigned long long same = __ballot(mine && my_xq == r.xq);
-                const unsigned long long within = __ballot(mine && star && d2mk < r2);
-                // an inserted sample inside the ball is a candidate parent unless its chord bound is not below the chosen cost
-                const unsigned long long cand =
-                    __ballot(mine && star && d2mk < r2 && my_cost + sqrt_u32(d2mk) * (1.0 - 1.0e-9) < r.cb);
-                if (nearer != 0ull || (pre_ok && same == 0ull && cand != 0ull)) break;  // resolved again next round, against the tree with them in
-                const bool acc = pre_ok && same == 0ull && j != n;  // rrt.py:425
-                sum_j += (unsigned long long)j;
-                sum_cells_nn += (unsigned long long)r.cells_nn;
-                n_words += (unsigned long long)r.nwords;
-                if (logs && lane == 0) {
-                    bv.nearest_log[(size_t)q * bv.n_cap + i + k] = (int32_t)r.nn_idx;
-                    bv.accept_log[(size_t)q * bv.n_cap + i + k] = (uint8_t)acc;
-                    bv.cbest_log[(size_t)q * bv.n_cap + i + k] = __longlong_as_double(0x7ff8000000000000ll);
-                    bv.j_log[(size_t)q * bv.n_cap + i + k] = j;
-                }
-                if (!acc) continue;
-                if (star) {
-                    sum_near += (unsigned long long)r.hits + (unsigned long long)__builtin_popcountll(within);
-                    n_los_cand += (unsigned long long)r.n_los;
-                    sum_cells_cand += (unsigned long long)r.cells_cand;
-                }
-                if (lane == 0) {  // rrt.py:524-529
-                    nodes_g[j] = r.xq;
-                    heading[j] = (uint8_t)r.hq;
-                    vcost[j] = r.cb;
-                    parent[j] = (int32_t)r.vb;
-                    const uint32_t cellb = (uint32_t)ux(r.xq) * (uint32_t)H + (uint32_t)uy(r.xq);
-                    atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
-                    const int c = cell_of(r.xq);
-                    const uint32_t pos = cellcnt[c];
-                    const unsigned long long cbits = (unsigned long long)__double_as_longlong(r.cb);
-                    cellrec[(size_t)c * (size_t)ccap + pos] = u32x4{r.xq, (uint32_t)j, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
-                    cellcnt[c] = pos + 1;
-                }
-                if (lane == k) my_cost = r.cb;
-                ins |= 1ull << k;
-                j++;
+            const bool in = lane < nb;
+            const DbRec r = L.rec[in ? lane : 0];
+            const bool pre_ok = in && (r.flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before this round
+            const int myc = cell_of(r.xq);
+            uint32_t same = 0, near_m = 0, within = 0, cand = 0, samecell = 0;  // bit m: against the earlier visible sample m
+            for (int m = 0; m + 1 < nb; ++m) {
+                const uint32_t xm = (uint32_t)__builtin_amdgcn_readlane((int)r.xq, m);
+                const bool pm = __builtin_amdgcn_readlane((int)pre_ok, m) != 0;
+                const unsigned long long cmb = (unsigned long long)__double_as_longlong(r.cb);
+                const double cm = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cmb >> 32), m) << 32) |
+                                                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cmb, m)));
+                if (!pm || lane <= m) continue;
+                const uint32_t d2 = dist2(xm, r.xq), bit = 1u << m;
+                same |= xm == r.xq ? bit : 0u;
+                near_m |= d2 < r.nn_d2 ? bit : 0u;
+                const bool inball = star && d2 < r2;
+                within |= inball ? bit : 0u;
+                cand |= (inball && cm + sqrt_u32(d2) * (1.0 - 1.0e-9) < r.cb) ? bit : 0u;
+                samecell |= cell_of(xm) == myc ? bit : 0u;
             }
-            i += k;  // k >= 1: sample 0 of a round has no earlier sample
+            const bool acc0 = pre_ok && same == 0u;  // the first visible sample on its cell
+            const uint32_t accm0 = (uint32_t)__ballot(acc0);
+            const bool dirty = in && ((near_m & accm0) != 0u || (acc0 && (cand & accm0) != 0u));
+            const unsigned long long dm = __ballot(dirty);
+            const int kcut = dm ? (int)__builtin_ctzll(dm) : nb;  // >= 1: sample 0 of a round has no earlier sample
+            const uint32_t lowk = (1u << lane) - 1u;
+            const int jk = j + __builtin_popcount(accm0 & lowk);  // j at the top of this lane's iteration
+            const bool acc = acc0 && jk < n && lane < kcut;       // rrt.py:425
+            const uint32_t accm = (uint32_t)__ballot(acc);
+            if (lane < kcut) {
+                L.stat[0][lane] += (unsigned long long)(jk < n ? jk : n);
+                L.stat[1][lane] += (unsigned long long)r.cells_nn;
+                L.stat[5][lane] += (unsigned long long)r.nwords;
+                if (logs) {
+                    bv.nearest_log[(size_t)q * bv.n_cap + i + lane] = (int32_t)r.nn_idx;
+                    bv.accept_log[(size_t)q * bv.n_cap + i + lane] = (uint8_t)acc;
+                    bv.cbest_log[(size_t)q * bv.n_cap + i + lane] = __longlong_as_double(0x7ff8000000000000ll);
+                    bv.j_log[(size_t)q * bv.n_cap + i + lane] = jk < n ? jk : n;
+                }
+            }
+            if (acc) {  // rrt.py:524-529
+                if (star) {
+                    L.stat[2][lane] += (unsigned long long)r.hits + (unsigned long long)__builtin_popcount(within & accm);
+                    L.stat[4][lane] += (unsigned long long)r.n_los;
+                    L.stat[3][lane] += (unsigned long long)r.cells_cand;
+                }
+                nodes_g[jk] = r.xq;
+                heading[jk] = (uint8_t)r.hq;
+                vcost[jk] = r.cb;
+                parent[jk] = (int32_t)r.vb;
+                const uint32_t cellb = (uint32_t)ux(r.xq) * (uint32_t)H + (uint32_t)uy(r.xq);
+                atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
+                const uint32_t pos = cellcnt[myc] + (uint32_t)__builtin_popcount(samecell & accm);  // (every lane reads the counts before any lane adds)
+                const unsigned long long cbits = (unsigned long long)__double_as_longlong(r.cb);
+                cellrec[(size_t)myc * (size_t)ccap + pos] = u32x4{r.xq, (uint32_t)jk, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+                __hip_atomic_fetch_add(&cellcnt[myc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            i += kcut;
+            j += __builtin_popcount(accm);
             if (lane == 0) {
                 L.st_i = i;
                 L.st_j = j;
@@ -454,6 +467,18 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
 
     for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
     __syncthreads();
+    unsigned long long sum_j = D->sum_j, sum_cells_nn = D->sum_cells_nn, sum_near = D->sum_near, sum_cells_cand = D->sum_cells_cand,
+                       n_los_cand = D->n_los_cand, n_words = D->n_words;
+    if (t == 0)
+        for (int k = 0; k < NWAVE; ++k) {
+            sum_j += L.stat[0][k];
+            sum_cells_nn += L.stat[1][k];
+            sum_near += L.stat[2][k];
+            sum_cells_cand += L.stat[3][k];
+            n_los_cand += L.stat[4][k];
+            n_words += L.stat[5][k];
+        }
+    __syncthreads();  // (go2goal reuses the LDS)
 
     // ---------------- go2goal (rrt.py:311-332) ----------------
     int status = ST_DONE, vgoal = 0, found = 0;
