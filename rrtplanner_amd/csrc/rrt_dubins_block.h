@@ -5,10 +5,15 @@
 // vertex on (x, y), sweep of the word nearest -> sample, accept test, choose parent over the radius ball, insert.  What is
 // expensive here is the word itself (~1150 dependent f64 operations), so the kernel is built around evaluating few of them:
 //
-//   rounds    the sample stream does not depend on the tree, so the 16 waves of the workgroup resolve 16 CONSECUTIVE samples
-//             side by side against the tree as it stands (one wave per sample), then wave 0 commits the longest prefix of them
-//             that no inserted sample of the same round can have influenced -- always at least one -- and the next round
-//             starts behind that prefix.  Results equal the sequential loop.
+//   pipeline  the sample stream does not depend on the tree, so the 16 waves of the workgroup each take the next sample off a
+//             ticket counter and resolve it on their own against the tree AS OF A SNAPSHOT (vertices [0, j_snap): the records
+//             carry the vertex index, younger ones are skipped), deposit the result in a ring in LDS and go on with the next
+//             ticket, at most DB_WIN samples ahead of retirement.  Samples RETIRE in order (whichever wave finds the head of
+//             the ring ready takes a lock and retires as far as it can): a sample is checked against the samples inserted since
+//             its snapshot -- one lane each -- and inserted or rejected if none of them can have influenced it; otherwise the
+//             retiring wave resolves it again, now against the exact tree (it is the head: nothing is in flight before it).
+//             No workgroup barrier in the loop: a sample that needs a second pass delays retirement, not the other waves.
+//             Results equal the sequential loop.
 //   nearest   every vertex also lives as a 16-byte record {xy, index, vcost} in the array of its cell of a uniform cell grid
 //             (the RRT* kernels' layout, rrt_block.h).  A wave streams the records of the cells its sample's radius ball touches
 //             as one packed stream; the nearest record of the box is near()[0] of the whole tree whenever it is no farther
@@ -32,28 +37,36 @@
 namespace rrtdev {
 
 constexpr int DB_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
+constexpr int DB_WIN = 32;   // samples in flight ahead of retirement
+constexpr unsigned long long DB_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
+constexpr int DB_RING = 64;  // ring of deposited / retired samples (>= 2 * DB_WIN: a retiring sample looks back at most DB_WIN - 1,
+                             // the youngest sample in flight is at most DB_WIN - 1 ahead of the head)
 
-// One sample as its wave resolved it against the tree of the round (64 bytes).
+// One sample as its wave resolved it against its snapshot of the tree (64 bytes); after retirement flags bit 2 says whether it
+// was inserted and cb is its vertex cost (what younger samples in flight are checked against).
 struct DbRec {
     uint32_t xq, hq;
-    uint32_t nn_idx, nn_d2;  // nearest vertex of the tree
-    uint32_t flags;          // bit 0: its word's sweep is free, bit 1: the sample's cell is already in `sampled`
+    uint32_t nn_idx, nn_d2;  // nearest vertex of the snapshot
+    uint32_t flags;          // bit 0: its word's sweep is free, bit 1: the sample's cell is already in `sampled`, bit 2: inserted (retired)
     uint32_t cells_nn;       // samples of that sweep read
-    uint32_t hits;           // |within| (RRT*)
+    uint32_t hits;           // |within| over the snapshot (RRT*)
     uint32_t vb;             // parent
     double cb;               // cost through the parent
-    uint32_t n_los, cells_cand, nwords, pad;
-    double pad2;
+    uint32_t n_los, cells_cand, nwords;
+    uint32_t snap_i;         // samples retired when it was resolved: it has seen exactly the samples before this one
+    uint32_t ready, pad;     // sample number + 1 once deposited (a slot is reused every DB_RING samples)
 };
 static_assert(sizeof(DbRec) == 64, "DbRec");
 
 struct DbLds {
     alignas(16) uint32_t cellcnt[MAX_CELLS];  // live fill counts of the cells; go2goal's two 8 KiB tables afterwards
     alignas(16) u32x4 buf[NWAVE][DB_BUF];     // pass 2: collected entries {xy, index, vcost}
-    alignas(16) DbRec rec[NWAVE];
+    alignas(16) DbRec ring[DB_RING];
     alignas(16) BSlot bslots[2 * NWAVE];
-    int32_t st_i, st_j;
-    unsigned long long stat[6][NWAVE];
+    alignas(8) unsigned long long state;  // samples retired << 32 | vertices: ONE word, so that a snapshot is consistent
+    uint32_t next, lock;                  // ticket counter, retirement lock
+    uint32_t fail;                        // a wave waited DB_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
+    unsigned long long stat[6];
 };
 
 // conservative single-precision lower bound of vcost + chord (see the head comment): below the f64 value by more than every
@@ -103,8 +116,14 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     }
 
     int i = D->i, j = D->j;
-    // statistics: per-lane sums of wave 0 in LDS (lane k: the samples it committed), folded once at the end
-    if (t < 6 * NWAVE) (&L.stat[0][0])[t] = 0ull;
+    if (t < 6) L.stat[t] = 0ull;  // statistics: added to by whoever retires (under the lock)
+    if (t < DB_RING) L.ring[t].ready = 0u;
+    if (t == 0) {
+        L.state = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)j;
+        L.next = (uint32_t)i;
+        L.lock = 0u;
+        L.fail = 0u;
+    }
 #ifdef RRT_STAMPS
     unsigned long long cyc[6] = {D->cyc[0], D->cyc[1], D->cyc[2], D->cyc[3], D->cyc[4], D->cyc[5]};
     unsigned long long tstamp = __builtin_amdgcn_s_memtime();
@@ -131,7 +150,8 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     // The records of the cells that the box of half-width `rad` around X touches, as ONE packed stream: lane l of a step takes
     // record 64 * step + l of the concatenation of the cells' arrays (exclusive prefix sum of the fill counts over the lanes, the
     // cell of a record by bisection over that prefix with ds_bpermute), 64 cells at a time.  f(record, live) once per step.
-    auto stream_box = [&](uint32_t X, int rad, auto &&f) {
+    // Records of vertices at or above `jsnap` (inserted after the caller's snapshot) are dealt as dead lanes.
+    auto stream_box = [&](uint32_t X, int rad, uint32_t jsnap, auto &&f) {
         const int x = ux(X), y = uy(X);
         const int cx0 = (x - rad < 0 ? 0 : x - rad) >> cshift, cx1 = (x + rad > W - 1 ? W - 1 : x + rad) >> cshift;
         const int cy0 = (y - rad < 0 ? 0 : y - rad) >> cshift, cy1 = (y + rad > H - 1 ? H - 1 : y + rad) >> cshift;
@@ -163,9 +183,9 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 }
                 const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
                 const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
-                const bool live = idx < total;
-                const u32x4 rc = cellrec[live ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
-                f(rc, live);
+                const bool inrange = idx < total;
+                const u32x4 rc = cellrec[inrange ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
+                f(rc, inrange && rc.y < jsnap);
             }
         }
     };
@@ -211,21 +231,138 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
         }
     };
 
+    // ---- retirement (under the lock): as far as the head of the ring is ready.  Returns the sample number of a head that has to
+    //      be resolved again against the exact tree (its deposit is withdrawn; the caller does it next), else -1. ----
+    auto try_retire = [&]() -> int {
+        for (;;) {
+            uint32_t got = 0;
+            if (lane == 0) got = __hip_atomic_compare_exchange_strong(&L.lock, &got, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+            if (__builtin_amdgcn_readfirstlane((int)got) == 0) return -1;  // somebody else is retiring; it looks at the head again before it leaves
+            int redo = -1;
+            for (;;) {
+                const unsigned long long st = __hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int h = (int)(st >> 32), jh = (int)(uint32_t)st;
+                if (h >= n) break;
+                DbRec *slot = &L.ring[h & (DB_RING - 1)];
+                if (__hip_atomic_load(&slot->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) break;
+                const DbRec r = *slot;
+                // against the samples inserted since its snapshot: lane l <-> sample snap_i + l (fewer than DB_WIN of them)
+                const int m = (int)r.snap_i + lane;
+                bool ins = false;
+                uint32_t xm = 0;
+                double cm = 0.0;
+                if (m < h) {
+                    const DbRec *e = &L.ring[m & (DB_RING - 1)];
+                    ins = (e->flags & 4u) != 0u;
+                    xm = e->xq;
+                    cm = e->cb;
+                }
+                const uint32_t d2 = dist2(xm, r.xq);
+                const bool pre_ok = (r.flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before its snapshot
+                const unsigned long long nearer = __ballot(ins && d2 < r.nn_d2);  // (a younger vertex loses ties: higher index)
+                const unsigned long long same = __ballot(ins && xm == r.xq);
+                const unsigned long long inball = __ballot(ins && star && d2 < r2);
+                // an inserted sample inside the ball is a candidate parent unless its chord bound is not below the chosen cost
+                const unsigned long long cand = __ballot(ins && star && d2 < r2 && cm + sqrt_u32(d2) * (1.0 - 1.0e-9) < r.cb);
+                if (nearer != 0ull || (pre_ok && same == 0ull && cand != 0ull)) {
+                    if (lane == 0) __hip_atomic_store(&slot->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    redo = h;
+                    break;
+                }
+                const bool acc = pre_ok && same == 0ull && jh != n;  // rrt.py:425
+                if (lane == 0) {
+                    L.stat[0] += (unsigned long long)jh;
+                    L.stat[1] += (unsigned long long)r.cells_nn;
+                    L.stat[5] += (unsigned long long)r.nwords;
+                    if (logs) {
+                        bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)r.nn_idx;
+                        bv.accept_log[(size_t)q * bv.n_cap + h] = (uint8_t)acc;
+                        bv.cbest_log[(size_t)q * bv.n_cap + h] = __longlong_as_double(0x7ff8000000000000ll);
+                        bv.j_log[(size_t)q * bv.n_cap + h] = jh;
+                    }
+                    if (acc) {  // rrt.py:524-529
+                        if (star) {
+                            L.stat[2] += (unsigned long long)r.hits + (unsigned long long)__builtin_popcountll(inball);
+                            L.stat[4] += (unsigned long long)r.n_los;
+                            L.stat[3] += (unsigned long long)r.cells_cand;
+                        }
+                        nodes_g[jh] = r.xq;
+                        heading[jh] = (uint8_t)r.hq;
+                        vcost[jh] = r.cb;
+                        parent[jh] = (int32_t)r.vb;
+                        const uint32_t cellb = (uint32_t)ux(r.xq) * (uint32_t)H + (uint32_t)uy(r.xq);
+                        atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
+                        const int c = cell_of(r.xq);
+                        const uint32_t pos = cellcnt[c];
+                        const unsigned long long cbits = (unsigned long long)__double_as_longlong(r.cb);
+                        cellrec[(size_t)c * (size_t)ccap + pos] = u32x4{r.xq, (uint32_t)jh, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+                        // the vertex, its heading and its record are in memory (acknowledged) before the fill count and the state name them
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        cellcnt[c] = pos + 1;
+                    }
+                    slot->flags = (r.flags & 3u) | (acc ? 4u : 0u);
+                    __hip_atomic_store(&L.state, ((unsigned long long)(uint32_t)(h + 1) << 32) | (uint32_t)(jh + (acc ? 1 : 0)), __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if (lane == 0) __hip_atomic_store(&L.lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (redo >= 0) return redo;
+            // a deposit that arrived while the lock was held found it taken and left: look at the head once more
+            const unsigned long long st = __hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int h = (int)(st >> 32);
+            if (h >= n || __hip_atomic_load(&L.ring[h & (DB_RING - 1)].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) return -1;
+        }
+    };
+
+    int mine = -1, redo = -1;  // a ticket taken but not resolved yet; a head to resolve again (first)
+    int wait_done = -1;        // bounded waiting: the retired count when this wave began to wait, and when
+    unsigned long long wait_t0 = 0;
     for (;;) {
-        if (i >= n) break;
-        const int nb = (n - i) < NWAVE ? (n - i) : NWAVE;  // samples of this round
-        // =============================== resolve: wave w takes sample i + w ===============================
-        if (wave < nb) {
-            const uint32_t xq = samples[i + wave];
-            const int hq = (int)shead[i + wave];
+        int s;
+        if (redo >= 0) {
+            s = redo;
+            redo = -1;
+        } else {
+            if (mine < 0) {
+                uint32_t tk = 0;
+                if (lane == 0) tk = __hip_atomic_fetch_add(&L.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                mine = __builtin_amdgcn_readfirstlane((int)tk);
+                if (mine > n) mine = n;  // (the counter runs on while the waves drain)
+            }
+            const int done = (int)(__hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
+            if (mine >= n && done >= n) break;
+            if (mine >= n || mine - done >= DB_WIN) {  // nothing left to take, or too far ahead of retirement: help retiring, wait
+                if (__hip_atomic_load(&L.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;
+                if (done != wait_done) {
+                    wait_done = done;
+                    wait_t0 = wall_clock64();
+                } else if (wall_clock64() - wait_t0 > DB_STALL_TICKS) {
+                    if (lane == 0) __hip_atomic_store(&L.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+                redo = try_retire();
+                if (redo < 0) __builtin_amdgcn_s_sleep(16);
+                DSTAMP(4);  // (diagnostic build, wave 0) waiting
+                continue;
+            }
+            s = mine;
+            mine = -1;
+        }
+        // =============================== resolve sample s against a snapshot ===============================
+        {
+            const unsigned long long snap = __hip_atomic_load(&L.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t snap_i = (uint32_t)(snap >> 32), jsnap = (uint32_t)snap;
+            const uint32_t xq = samples[s];
+            const int hq = (int)shead[s];
             const uint32_t cell = (uint32_t)ux(xq) * (uint32_t)H + (uint32_t)uy(xq);
-            const uint32_t bm_word = bitmap[cell >> 5];
+            const uint32_t bm_word = __hip_atomic_load(bitmap + (cell >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (set by an L2 atomic: read it there)
             // ---- pass 1 of the record stream: nearest record of the box, |within|, per lane the entry with the smallest bound ----
             uint32_t hits = 0;
             uint32_t ld2 = NONE, lidx = NONE, lxy = 0, lvl = 0, lvh = 0;  // this lane's nearest record
             float m1f = FINF, m2f = FINF;                                 // smallest / second smallest bound among this lane's hits
             uint32_t m1idx = NONE, m1xy = 0, m1vl = 0, m1vh = 0;
-            stream_box(xq, rad0, [&](const u32x4 rc, bool live) {
+            stream_box(xq, rad0, jsnap, [&](const u32x4 rc, bool live) {
                 const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                 const bool nearer = d2 < ld2 || (d2 == ld2 && live && rc.y < lidx);
                 ld2 = nearer ? d2 : ld2;
@@ -254,7 +391,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 radn = 2 * radn + 1;
                 ld2 = NONE;
                 lidx = NONE;
-                stream_box(xq, radn, [&](const u32x4 rc, bool live) {
+                stream_box(xq, radn, jsnap, [&](const u32x4 rc, bool live) {
                     const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                     const bool nearer = d2 < ld2 || (d2 == ld2 && live && rc.y < lidx);
                     ld2 = nearer ? d2 : ld2;
@@ -353,7 +490,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                         if (tail) buf[lane] = mv;
                         nbuf = nbuf > 64u ? nbuf - 64u : 0u;
                     };
-                    stream_box(xq, rad0, [&](const u32x4 rc, bool live) {
+                    stream_box(xq, rad0, jsnap, [&](const u32x4 rc, bool live) {
                         const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                         const double V = __longlong_as_double((long long)(((unsigned long long)rc.w << 32) | rc.z));
                         const bool take = d2 < r2 && rc.y != nn_idx && rc.y != skip && (double)db_lower_bound(V, d2) < cb;
@@ -369,6 +506,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             }
             DSTAMP(2);
             if (lane == 0) {
+                DbRec *slot = &L.ring[s & (DB_RING - 1)];
                 DbRec r;
                 r.xq = xq;
                 r.hq = (uint32_t)hq;
@@ -382,107 +520,40 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 r.n_los = nlos;
                 r.cells_cand = ccells;
                 r.nwords = nwords;
-                r.pad = 0;
-                r.pad2 = 0.0;
-                L.rec[wave] = r;
+                r.snap_i = snap_i;
+                r.ready = 0u;
+                r.pad = 0u;
+                *slot = r;
+                __hip_atomic_store(&slot->ready, (uint32_t)s + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        __syncthreads();
-        DSTAMP(4);  // wave 0's wait for the slowest wave of the round
-        // =============================== commit: wave 0, one lane per sample ===============================
-        // The longest prefix of the round that no inserted sample of the same round can have influenced.  Sample k is touched by an
-        // earlier INSERTED sample m when m is nearer than k's nearest vertex (a new vertex loses ties: higher index), or -- k
-        // visible and on a new cell -- when m lies in k's ball with a chord bound below k's chosen cost.  Which samples are
-        // inserted is known up front: the first visible sample on a cell (rrt.py:425), while the tree is not full.
-        if (wave == 0) {
-            const bool in = lane < nb;
-            const DbRec r = L.rec[in ? lane : 0];
-            const bool pre_ok = in && (r.flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before this round
-            const int myc = cell_of(r.xq);
-            uint32_t same = 0, near_m = 0, within = 0, cand = 0, samecell = 0;  // bit m: against the earlier visible sample m
-            for (int m = 0; m + 1 < nb; ++m) {
-                const uint32_t xm = (uint32_t)__builtin_amdgcn_readlane((int)r.xq, m);
-                const bool pm = __builtin_amdgcn_readlane((int)pre_ok, m) != 0;
-                const unsigned long long cmb = (unsigned long long)__double_as_longlong(r.cb);
-                const double cm = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cmb >> 32), m) << 32) |
-                                                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cmb, m)));
-                if (!pm || lane <= m) continue;
-                const uint32_t d2 = dist2(xm, r.xq), bit = 1u << m;
-                same |= xm == r.xq ? bit : 0u;
-                near_m |= d2 < r.nn_d2 ? bit : 0u;
-                const bool inball = star && d2 < r2;
-                within |= inball ? bit : 0u;
-                cand |= (inball && cm + sqrt_u32(d2) * (1.0 - 1.0e-9) < r.cb) ? bit : 0u;
-                samecell |= cell_of(xm) == myc ? bit : 0u;
-            }
-            const bool acc0 = pre_ok && same == 0u;  // the first visible sample on its cell
-            const uint32_t accm0 = (uint32_t)__ballot(acc0);
-            const bool dirty = in && ((near_m & accm0) != 0u || (acc0 && (cand & accm0) != 0u));
-            const unsigned long long dm = __ballot(dirty);
-            const int kcut = dm ? (int)__builtin_ctzll(dm) : nb;  // >= 1: sample 0 of a round has no earlier sample
-            const uint32_t lowk = (1u << lane) - 1u;
-            const int jk = j + __builtin_popcount(accm0 & lowk);  // j at the top of this lane's iteration
-            const bool acc = acc0 && jk < n && lane < kcut;       // rrt.py:425
-            const uint32_t accm = (uint32_t)__ballot(acc);
-            if (lane < kcut) {
-                L.stat[0][lane] += (unsigned long long)(jk < n ? jk : n);
-                L.stat[1][lane] += (unsigned long long)r.cells_nn;
-                L.stat[5][lane] += (unsigned long long)r.nwords;
-                if (logs) {
-                    bv.nearest_log[(size_t)q * bv.n_cap + i + lane] = (int32_t)r.nn_idx;
-                    bv.accept_log[(size_t)q * bv.n_cap + i + lane] = (uint8_t)acc;
-                    bv.cbest_log[(size_t)q * bv.n_cap + i + lane] = __longlong_as_double(0x7ff8000000000000ll);
-                    bv.j_log[(size_t)q * bv.n_cap + i + lane] = jk < n ? jk : n;
-                }
-            }
-            if (acc) {  // rrt.py:524-529
-                if (star) {
-                    L.stat[2][lane] += (unsigned long long)r.hits + (unsigned long long)__builtin_popcount(within & accm);
-                    L.stat[4][lane] += (unsigned long long)r.n_los;
-                    L.stat[3][lane] += (unsigned long long)r.cells_cand;
-                }
-                nodes_g[jk] = r.xq;
-                heading[jk] = (uint8_t)r.hq;
-                vcost[jk] = r.cb;
-                parent[jk] = (int32_t)r.vb;
-                const uint32_t cellb = (uint32_t)ux(r.xq) * (uint32_t)H + (uint32_t)uy(r.xq);
-                atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
-                const uint32_t pos = cellcnt[myc] + (uint32_t)__builtin_popcount(samecell & accm);  // (every lane reads the counts before any lane adds)
-                const unsigned long long cbits = (unsigned long long)__double_as_longlong(r.cb);
-                cellrec[(size_t)myc * (size_t)ccap + pos] = u32x4{r.xq, (uint32_t)jk, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
-                __hip_atomic_fetch_add(&cellcnt[myc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            i += kcut;
-            j += __builtin_popcount(accm);
-            if (lane == 0) {
-                L.st_i = i;
-                L.st_j = j;
-            }
-        }
-        __syncthreads();  // the inserted vertices, their records and the fill counts are visible to every wave
-        i = L.st_i;
-        j = L.st_j;
-        DSTAMP(5);  // commit + publication
+        redo = try_retire();
+        DSTAMP(5);  // deposit + retirement
+    }
+    __syncthreads();
+    {
+        const unsigned long long st = __hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        i = (int)(st >> 32);
+        j = (int)(uint32_t)st;
     }
 
     for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
     __syncthreads();
     unsigned long long sum_j = D->sum_j, sum_cells_nn = D->sum_cells_nn, sum_near = D->sum_near, sum_cells_cand = D->sum_cells_cand,
                        n_los_cand = D->n_los_cand, n_words = D->n_words;
-    if (t == 0)
-        for (int k = 0; k < NWAVE; ++k) {
-            sum_j += L.stat[0][k];
-            sum_cells_nn += L.stat[1][k];
-            sum_near += L.stat[2][k];
-            sum_cells_cand += L.stat[3][k];
-            n_los_cand += L.stat[4][k];
-            n_words += L.stat[5][k];
-        }
+    sum_j += L.stat[0];
+    sum_cells_nn += L.stat[1];
+    sum_near += L.stat[2];
+    sum_cells_cand += L.stat[3];
+    n_los_cand += L.stat[4];
+    n_words += L.stat[5];
     __syncthreads();  // (go2goal reuses the LDS)
 
     // ---------------- go2goal (rrt.py:311-332) ----------------
     int status = ST_DONE, vgoal = 0, found = 0;
-    {
+    if (L.fail != 0u || i < n) {
+        status = ST_TEAM_FAIL;  // (reported as RRT_E_HIP; the tree is consistent up to sample i)
+    } else {
         double pc;
         uint32_t pi;
         go2goal_phase<true>(og, H, nodes_g, vcost, 0, 1, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)L.cellcnt, L.bslots, t, lane, wave, pc, pi,
