@@ -37,9 +37,9 @@
 namespace rrtdev {
 
 constexpr int DB_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
-constexpr int DB_WIN = 32;   // samples in flight ahead of retirement
+constexpr int DB_WIN = 64;   // samples in flight ahead of retirement
 constexpr unsigned long long DB_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
-constexpr int DB_RING = 64;  // ring of deposited / retired samples (>= 2 * DB_WIN: a retiring sample looks back at most DB_WIN - 1,
+constexpr int DB_RING = 128; // ring of deposited / retired samples (>= 2 * DB_WIN: a retiring sample looks back at most DB_WIN - 1,
                              // the youngest sample in flight is at most DB_WIN - 1 ahead of the head)
 
 // One sample as its wave resolved it against its snapshot of the tree (64 bytes); after retirement flags bit 2 says whether it
@@ -54,7 +54,8 @@ struct DbRec {
     double cb;               // cost through the parent
     uint32_t n_los, cells_cand, nwords;
     uint32_t snap_i;         // samples retired when it was resolved: it has seen exactly the samples before this one
-    uint32_t ready, pad;     // sample number + 1 once deposited (a slot is reused every DB_RING samples)
+    uint32_t ready;          // sample number + 1 once deposited (a slot is reused every DB_RING samples)
+    uint32_t vidx;           // after retirement: its vertex
 };
 static_assert(sizeof(DbRec) == 64, "DbRec");
 
@@ -67,6 +68,7 @@ struct DbLds {
     uint32_t next, lock;                  // ticket counter, retirement lock
     uint32_t fail;                        // a wave waited DB_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
     unsigned long long stat[6];
+    unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, [1] retirements that priced younger vertices, [2] those vertices
 };
 
 // conservative single-precision lower bound of vcost + chord (see the head comment): below the f64 value by more than every
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
 
     int i = D->i, j = D->j;
     if (t < 6) L.stat[t] = 0ull;  // statistics: added to by whoever retires (under the lock)
+    if (t < 8) L.dbg[t] = 0ull;
     if (t < DB_RING) L.ring[t].ready = 0u;
     if (t == 0) {
         L.state = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)j;
@@ -239,41 +242,97 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             if (lane == 0) got = __hip_atomic_compare_exchange_strong(&L.lock, &got, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
             if (__builtin_amdgcn_readfirstlane((int)got) == 0) return -1;  // somebody else is retiring; it looks at the head again before it leaves
             int redo = -1;
+            const unsigned long long st0 = __hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int h = (int)(st0 >> 32), jh = (int)(uint32_t)st0;  // local while the lock is held; published in batches
+            const int h0 = h;
+            // Insertions of this batch whose fill counts are not published yet: lane k holds the cell of the k-th.  The vertices'
+            // stores are acknowledged ONCE per batch (s_waitcnt vmcnt(0)), then the counts and the state name them.
+            uint32_t pend_cell = NONE;
+            int npend = 0;
+            auto publish = [&]() {
+                if (h == h0 && npend == 0) return;
+                if (npend > 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane < npend) __hip_atomic_fetch_add(&cellcnt[pend_cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (lane == 0)
+                    __hip_atomic_store(&L.state, ((unsigned long long)(uint32_t)h << 32) | (uint32_t)jh, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pend_cell = NONE;
+                npend = 0;
+            };
             for (;;) {
-                const unsigned long long st = __hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int h = (int)(st >> 32), jh = (int)(uint32_t)st;
                 if (h >= n) break;
                 DbRec *slot = &L.ring[h & (DB_RING - 1)];
                 if (__hip_atomic_load(&slot->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) break;
-                const DbRec r = *slot;
+                DbRec r = *slot;
                 // against the samples inserted since its snapshot: lane l <-> sample snap_i + l (fewer than DB_WIN of them)
                 const int m = (int)r.snap_i + lane;
                 bool ins = false;
-                uint32_t xm = 0;
+                uint32_t xm = 0, hm = 0, vm = NONE;
                 double cm = 0.0;
                 if (m < h) {
                     const DbRec *e = &L.ring[m & (DB_RING - 1)];
                     ins = (e->flags & 4u) != 0u;
                     xm = e->xq;
+                    hm = e->hq;
+                    vm = e->vidx;
                     cm = e->cb;
                 }
                 const uint32_t d2 = dist2(xm, r.xq);
                 const bool pre_ok = (r.flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before its snapshot
-                const unsigned long long nearer = __ballot(ins && d2 < r.nn_d2);  // (a younger vertex loses ties: higher index)
-                const unsigned long long same = __ballot(ins && xm == r.xq);
-                const unsigned long long inball = __ballot(ins && star && d2 < r2);
-                // an inserted sample inside the ball is a candidate parent unless its chord bound is not below the chosen cost
-                const unsigned long long cand = __ballot(ins && star && d2 < r2 && cm + sqrt_u32(d2) * (1.0 - 1.0e-9) < r.cb);
-                if (nearer != 0ull || (pre_ok && same == 0ull && cand != 0ull)) {
+                if (__ballot(ins && d2 < r.nn_d2) != 0ull) {  // a younger vertex is nearer (it loses ties: higher index): resolve again
                     if (lane == 0) __hip_atomic_store(&slot->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     redo = h;
+#ifdef RRT_STAMPS
+                    if (lane == 0) L.dbg[0] += 1;
+#endif
                     break;
                 }
+                const unsigned long long same = __ballot(ins && xm == r.xq);
+                const unsigned long long inball = __ballot(ins && star && d2 < r2);
+                uint32_t add_los = 0, add_cells = 0, add_words = 0;
+                if (pre_ok && same == 0ull) {
+                    // A younger vertex inside the ball is one more candidate parent (rrt.py:515-521 walks it too) unless its chord
+                    // bound is not below the chosen cost: price those, one word per lane, and sweep the ones below it (a younger
+                    // vertex loses every tie: higher index than the snapshot's choice)
+                    const bool cnd = ins && star && d2 < r2 && cm + sqrt_u32(d2) * (1.0 - 1.0e-9) < r.cb;
+                    if (__ballot(cnd) != 0ull) {
+                        dub_path_t wp;
+                        wp.t = wp.p = wp.q = 0.0;
+                        wp.len = f64_inf();
+                        wp.word = DUB_NONE;
+                        double wcn = f64_inf();
+                        if (cnd) {
+                            wp = dub_between_dev(xm, (int)hm, r.xq, (int)r.hq, dc);
+                            wcn = cm + wp.len;
+                        }
+                        add_words = (uint32_t)__builtin_popcountll(__ballot(cnd));
+#ifdef RRT_STAMPS
+                        if (lane == 0) {
+                            L.dbg[1] += 1;
+                            L.dbg[2] += add_words;
+                        }
+#endif
+                        double cb = r.cb;
+                        uint32_t vb = r.vb;
+                        test_priced(cnd, wcn, vm, xm, (int)hm, wp, r.xq, cb, vb, add_los, add_cells);
+                        r.cb = cb;
+                        r.vb = vb;
+                    }
+                }
                 const bool acc = pre_ok && same == 0ull && jh != n;  // rrt.py:425
+                int c = 0;
+                uint32_t pos = 0;
+                if (acc) {
+                    c = cell_of(r.xq);
+                    pos = cellcnt[c] + (uint32_t)__builtin_popcountll(__ballot(pend_cell == (uint32_t)c));
+                    if (lane == npend) pend_cell = (uint32_t)c;
+                }
                 if (lane == 0) {
                     L.stat[0] += (unsigned long long)jh;
                     L.stat[1] += (unsigned long long)r.cells_nn;
-                    L.stat[5] += (unsigned long long)r.nwords;
+                    L.stat[5] += (unsigned long long)(r.nwords + add_words);
                     if (logs) {
                         bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)r.nn_idx;
                         bv.accept_log[(size_t)q * bv.n_cap + h] = (uint8_t)acc;
@@ -283,8 +342,8 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                     if (acc) {  // rrt.py:524-529
                         if (star) {
                             L.stat[2] += (unsigned long long)r.hits + (unsigned long long)__builtin_popcountll(inball);
-                            L.stat[4] += (unsigned long long)r.n_los;
-                            L.stat[3] += (unsigned long long)r.cells_cand;
+                            L.stat[4] += (unsigned long long)(r.n_los + add_los);
+                            L.stat[3] += (unsigned long long)(r.cells_cand + add_cells);
                         }
                         nodes_g[jh] = r.xq;
                         heading[jh] = (uint8_t)r.hq;
@@ -292,25 +351,23 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                         parent[jh] = (int32_t)r.vb;
                         const uint32_t cellb = (uint32_t)ux(r.xq) * (uint32_t)H + (uint32_t)uy(r.xq);
                         atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
-                        const int c = cell_of(r.xq);
-                        const uint32_t pos = cellcnt[c];
                         const unsigned long long cbits = (unsigned long long)__double_as_longlong(r.cb);
                         cellrec[(size_t)c * (size_t)ccap + pos] = u32x4{r.xq, (uint32_t)jh, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
-                        // the vertex, its heading and its record are in memory (acknowledged) before the fill count and the state name them
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        cellcnt[c] = pos + 1;
                     }
+                    // what younger samples in flight are checked against (read under the lock only)
                     slot->flags = (r.flags & 3u) | (acc ? 4u : 0u);
-                    __hip_atomic_store(&L.state, ((unsigned long long)(uint32_t)(h + 1) << 32) | (uint32_t)(jh + (acc ? 1 : 0)), __ATOMIC_RELEASE,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    slot->cb = r.cb;
+                    slot->vidx = (uint32_t)jh;
                 }
+                npend += acc ? 1 : 0;
+                jh += acc ? 1 : 0;
+                h += 1;
+                if (npend == 16) publish();
             }
+            publish();
             if (lane == 0) __hip_atomic_store(&L.lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (redo >= 0) return redo;
             // a deposit that arrived while the lock was held found it taken and left: look at the head once more
-            const unsigned long long st = __hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int h = (int)(st >> 32);
             if (h >= n || __hip_atomic_load(&L.ring[h & (DB_RING - 1)].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) return -1;
         }
     };
@@ -522,7 +579,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 r.nwords = nwords;
                 r.snap_i = snap_i;
                 r.ready = 0u;
-                r.pad = 0u;
+                r.vidx = NONE;
                 *slot = r;
                 __hip_atomic_store(&slot->ready, (uint32_t)s + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -586,6 +643,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
         D->n_words = n_words;
 #ifdef RRT_STAMPS
         for (int k = 0; k < 6; ++k) D->cyc[k] = cyc[k];
+        for (int k = 0; k < 8; ++k) D->wcyc[k] = L.dbg[k];
 #endif
     }
 }

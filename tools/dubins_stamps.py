@@ -38,3 +38,6 @@ names = (["A scan", "pricing (wave 0's entries)", "wait for the nearest's word +
 tot = sum(cyc[:6]) or 1
 for nm, c in zip(names, cyc[:6]): print("  %-32s %12d  %5.1f%%  %8.1f cyc/iter" % (nm, c, 100 * c / tot, c / n))
 print("near", r.c.sum_near / n, "los_cand", r.c.n_los_cand / n)
+if not serial:
+    print("samples resolved again (a younger vertex nearer than the snapshot nearest): %d (%.2f %%);  retirements that priced younger vertices: %d (%.2f %%), %d words" % (
+        cyc[6], 100.0 * cyc[6] / n, cyc[7], 100.0 * cyc[7] / n, cyc[8]))
