@@ -183,6 +183,24 @@ int rrt_plan(rrt_ctx *ctx, const rrt_query *query, uint32_t flags, rrt_result *o
 int rrt_plan_resume(rrt_ctx *ctx, const double *unitball, int32_t count, rrt_result *out);
 int rrt_plan_batch(rrt_ctx *ctx, int32_t Q, const rrt_query *queries, rrt_result *out);
 
+/* ---- host-driven planners: a caller-supplied cost function (rrt.py:55, :70-80 accepts any Python callable) cannot run on the
+ * device, so for such a planner the loop of rrt.py:498-548 / :690-748 stays on the host and asks the device, once per
+ * iteration, for what it needs of the tree and the grid: near()[0], within() and the lines of sight of rrt.py:506, :519, :537.
+ * The vertex list lives on the device (one 4-byte append per accepted sample). -------------------------------------------- */
+typedef struct rrt_tree rrt_tree;
+int rrt_tree_create(rrt_ctx *ctx, int32_t capacity, rrt_tree **out);
+int rrt_tree_destroy(rrt_tree *t);
+int rrt_tree_reset(rrt_tree *t); /* no vertices */
+/* points[j] = (x, y) for the next free row j (rrt.py:411, :525); *index receives j.  Asynchronous. */
+int rrt_tree_append(rrt_tree *t, int32_t x, int32_t y, int32_t *index);
+/* One iteration's questions about sample (x, y), against the context's current grid:
+ *   *nearest       near(points, x)[0] over the live rows, lowest index among equal distance          (rrt.py:503)
+ *   *within_count  number of live rows with d2 < r2; within_idx[0 .. min(count, cap)) their indices, ascending (rrt.py:513)
+ *   los_free[0]    collisionfree(og, points[nearest], x);  los_free[1 + k] = collisionfree(og, points[within_idx[k]], x)
+ * los_free holds cap + 1 bytes.  RRT_E_ARG when the tree is empty or (x, y) lies outside the grid. */
+int rrt_tree_query(rrt_tree *t, int32_t x, int32_t y, int64_t r2, int32_t *nearest, int32_t *within_count, int32_t *within_idx, uint8_t *los_free,
+                   int32_t cap);
+
 /* ---- primitives of the path (parity tests, micro-benchmarks) --------------------------- */
 /* RRT.collisionfree (rrt.py:183-229) for m segments ab[k] = {ax,ay,bx,by}; cells = grid cells the
  * reference's walk reads before it returns. */

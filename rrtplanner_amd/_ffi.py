@@ -57,6 +57,7 @@ SYMBOLS = (
     "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_pipelined", "rrt_batch_kernel_name", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
     "rrt_plan", "rrt_plan_resume", "rrt_plan_batch",
+    "rrt_tree_create", "rrt_tree_destroy", "rrt_tree_reset", "rrt_tree_append", "rrt_tree_query",
     "rrt_prim_collisionfree", "rrt_prim_nearest_within", "rrt_prim_sqrt_u32", "rrt_prim_sqrt_u24", "rrt_prim_sqrt_f64",
 )
 
@@ -138,6 +139,11 @@ def lib():
             "rrt_plan": ([vp, C.POINTER(Query), u32, C.POINTER(Result)], C.c_int),
             "rrt_plan_resume": ([vp, vp, i32, C.POINTER(Result)], C.c_int),
             "rrt_plan_batch": ([vp, i32, C.POINTER(Query), C.POINTER(Result)], C.c_int),
+            "rrt_tree_create": ([vp, i32, C.POINTER(vp)], C.c_int),
+            "rrt_tree_destroy": ([vp], C.c_int),
+            "rrt_tree_reset": ([vp], C.c_int),
+            "rrt_tree_append": ([vp, i32, i32, C.POINTER(i32)], C.c_int),
+            "rrt_tree_query": ([vp, i32, i32, i64, C.POINTER(i32), C.POINTER(i32), vp, vp, i32], C.c_int),
             "rrt_prim_collisionfree": ([vp, vp, i32, vp, vp], C.c_int),
             "rrt_prim_nearest_within": ([vp, vp, i32, vp, i32, i64, vp, vp, vp], C.c_int),
             "rrt_prim_sqrt_u32": ([vp, u32, u32, vp], C.c_int),
@@ -368,6 +374,49 @@ class Context:
         out = np.zeros_like(x)
         _check(self._h, lib().rrt_prim_sqrt_f64(self._h, x.ctypes.data, x.size, out.ctypes.data))
         return out
+
+
+class DeviceTree:
+    """The device-resident vertex list of a host-driven planner (rrt_tree_*): the planner keeps its loop -- and its Python
+    cost function -- on the host and asks the device once per iteration for near()[0], within() and the lines of sight."""
+
+    def __init__(self, ctx: Context, capacity: int):
+        self.ctx, self.capacity = ctx, int(capacity)
+        self._h = C.c_void_p()
+        _check(ctx.handle, lib().rrt_tree_create(ctx.handle, self.capacity, C.byref(self._h)))
+        if not hasattr(ctx, "_batches"):
+            ctx._batches = weakref.WeakSet()
+        ctx._batches.add(self)  # closed before the context, like a batch
+        self._idx = np.zeros(self.capacity, dtype=np.int32)
+        self._los = np.zeros(self.capacity + 1, dtype=np.uint8)
+
+    def close(self):
+        if self._h:
+            lib().rrt_tree_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _check(self.ctx.handle, lib().rrt_tree_reset(self._h))
+
+    def append(self, x, y) -> int:
+        j = C.c_int32(-1)
+        _check(self.ctx.handle, lib().rrt_tree_append(self._h, int(x), int(y), C.byref(j)))
+        return j.value
+
+    def query(self, x, y, r2):
+        """(nearest vertex, ascending indices of the vertices with d2 < r2, line of sight nearest -> (x, y),
+        lines of sight of those vertices -> (x, y))"""
+        nn, cnt = C.c_int32(-1), C.c_int32(0)
+        _check(self.ctx.handle, lib().rrt_tree_query(self._h, int(x), int(y), int(r2), C.byref(nn), C.byref(cnt), self._idx.ctypes.data,
+                                                     self._los.ctypes.data, self.capacity))
+        m = cnt.value
+        return nn.value, self._idx[:m].copy(), bool(self._los[0]), self._los[1:1 + m].astype(bool)
 
 
 class Batch:

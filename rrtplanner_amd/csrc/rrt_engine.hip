@@ -1251,6 +1251,112 @@ extern "C" int rrt_plan_batch(rrt_ctx *ctx, int32_t Q, const rrt_query *queries,
     return rc != RRT_OK ? rc : worst;
 }
 
+// ---- host-driven planners (custom cost functions): the device-resident vertex list and its per-iteration query --------------
+struct rrt_tree {
+    rrt_ctx *ctx = nullptr;
+    int32_t cap = 0, j = 0;
+    uint32_t *d_nodes = nullptr;
+    uint32_t *h_nodes = nullptr;  // page-locked mirror: an append is one 4-byte copy in stream order
+    int32_t *d_out = nullptr;     // [2 + cap]
+    uint8_t *d_los = nullptr;     // [1 + cap]
+    int32_t *h_out = nullptr;     // page-locked [2 + cap]
+    uint8_t *h_los = nullptr;     // page-locked [1 + cap]
+};
+
+extern "C" int rrt_tree_destroy(rrt_tree *t) {
+    if (!t) return RRT_OK;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    if (t->d_nodes) (void)hipFree(t->d_nodes);
+    if (t->d_out) (void)hipFree(t->d_out);
+    if (t->d_los) (void)hipFree(t->d_los);
+    if (t->h_nodes) (void)hipHostFree(t->h_nodes);
+    if (t->h_out) (void)hipHostFree(t->h_out);
+    if (t->h_los) (void)hipHostFree(t->h_los);
+    delete t;
+    return RRT_OK;
+}
+
+extern "C" int rrt_tree_create(rrt_ctx *ctx, int32_t capacity, rrt_tree **out) {
+    if (!ctx || !out || capacity < 1) return fail(ctx, RRT_E_ARG, "rrt_tree_create: bad argument");
+    if ((long long)capacity > 64LL * CHUNK) return fail(ctx, RRT_E_UNSUPPORTED, "rrt_tree_create: capacity %d exceeds %d vertices", capacity, 64 * CHUNK);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rrt_tree *t = new rrt_tree();
+    t->ctx = ctx;
+    t->cap = capacity;
+    const size_t c = (size_t)capacity;
+    hipError_t e = hipMalloc((void **)&t->d_nodes, c * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_out, (c + 2) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&t->d_los, c + 1);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&t->h_nodes, c * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&t->h_out, (c + 2) * sizeof(int32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&t->h_los, c + 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        rrt_tree_destroy(t);
+        return fail(ctx, RRT_E_HIP, "rrt_tree_create: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return RRT_OK;
+}
+
+extern "C" int rrt_tree_reset(rrt_tree *t) {
+    if (!t) return fail(nullptr, RRT_E_ARG, "rrt_tree_reset: NULL");
+    HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
+    HIPCHK(t->ctx, hipStreamSynchronize(t->ctx->stream));  // an append still in flight reads the mirror
+    t->j = 0;
+    return RRT_OK;
+}
+
+extern "C" int rrt_tree_append(rrt_tree *t, int32_t x, int32_t y, int32_t *index) {
+    if (!t) return fail(nullptr, RRT_E_ARG, "rrt_tree_append: NULL");
+    rrt_ctx *ctx = t->ctx;
+    if (t->j >= t->cap) return fail(ctx, RRT_E_ARG, "rrt_tree_append: the tree holds its %d vertices", t->cap);
+    if (x < 0 || x >= 2048 || y < 0 || y >= 2048) return fail(ctx, RRT_E_ARG, "rrt_tree_append: (%d, %d) outside [0, 2048)^2", x, y);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    t->h_nodes[t->j] = ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16);
+    HIPCHK(ctx, hipMemcpyAsync(t->d_nodes + t->j, t->h_nodes + t->j, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (index) *index = t->j;
+    t->j += 1;
+    return RRT_OK;
+}
+
+extern "C" int rrt_tree_query(rrt_tree *t, int32_t x, int32_t y, int64_t r2, int32_t *nearest, int32_t *within_count, int32_t *within_idx,
+                              uint8_t *los_free, int32_t cap) {
+    if (!t || !nearest || !within_count || cap < 0 || (cap > 0 && (!within_idx || !los_free)) || !los_free)
+        return fail(t ? t->ctx : nullptr, RRT_E_ARG, "rrt_tree_query: bad argument");
+    rrt_ctx *ctx = t->ctx;
+    if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_tree_query: no grid");
+    if (t->j < 1) return fail(ctx, RRT_E_ARG, "rrt_tree_query: the tree is empty");
+    if (x < 0 || x >= ctx->W || y < 0 || y >= ctx->H) return fail(ctx, RRT_E_ARG, "rrt_tree_query: (%d, %d) outside the %dx%d grid", x, y, ctx->W, ctx->H);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int dcap = cap < t->cap ? cap : t->cap;
+    const int64_t capd2 = 1 << 24;
+    const uint32_t r2c = (uint32_t)(r2 < 0 ? 0 : (r2 > capd2 ? capd2 : r2));
+    const uint32_t xq = ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16);
+    hipLaunchKernelGGL(tree_query_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->og, ctx->H, t->d_nodes, t->j, xq, r2c, dcap, t->d_out, t->d_los);
+    HIPCHK(ctx, hipGetLastError());
+    // the usual answer (a few dozen rows) comes back in one copy of each array; a longer list in a second pair
+    const int first = dcap < 256 ? dcap : 256;
+    HIPCHK(ctx, hipMemcpyAsync(t->h_out, t->d_out, (size_t)(2 + first) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(t->h_los, t->d_los, (size_t)(1 + first), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, wait_stream_spin(ctx->stream));
+    const int total = t->h_out[1];
+    const int have = total < dcap ? total : dcap;
+    if (have > first) {
+        HIPCHK(ctx, hipMemcpyAsync(t->h_out + 2 + first, t->d_out + 2 + first, (size_t)(have - first) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(t->h_los + 1 + first, t->d_los + 1 + first, (size_t)(have - first), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, wait_stream_spin(ctx->stream));
+    }
+    *nearest = t->h_out[0];
+    *within_count = total;
+    los_free[0] = t->h_los[0];
+    for (int k = 0; k < have; ++k) {
+        within_idx[k] = t->h_out[2 + k];
+        los_free[1 + k] = t->h_los[1 + k];
+    }
+    return RRT_OK;
+}
+
 // ---- primitives ---------------------------------------------------------------------------
 
 extern "C" int rrt_prim_collisionfree(rrt_ctx *ctx, const int32_t *ab, int32_t m, uint8_t *out_free, int32_t *out_cells) {

@@ -81,6 +81,73 @@ __global__ __launch_bounds__(TPB) void prim_nn_kernel(const uint32_t *nodes, int
     }
 }
 
+// One iteration's worth of primitives for a HOST-DRIVEN planner (a custom Python cost function keeps the loop of
+// rrt.py:498-548 on the host; the device answers what the loop asks of the tree and the grid):
+//   out[0]      near()[0]   (rrt.py:150-155, :503): nearest vertex of the j live rows, lowest index among equal distance
+//   out[1]      |within()|  (rrt.py:176-181, :513): live rows with d2 < r2
+//   out[2 + k]  their indices, ascending, the first `cap` of them
+//   los[0]      collisionfree(nearest -> x)        (rrt.py:506)
+//   los[1 + k]  collisionfree(within[k] -> x)      (rrt.py:519, :537: the same direction in both loops)
+// One workgroup; thread t owns the contiguous rows [t * per, (t + 1) * per), so that its hits are ascending and the
+// hits of the threads concatenate in ascending order (exclusive prefix sum of the per-thread counts).
+__global__ __launch_bounds__(TPB) void tree_query_kernel(const uint8_t *og, int H, const uint32_t *nodes, int j, uint32_t xq, uint32_t r2, int cap,
+                                                         int32_t *out, uint8_t *los) {
+    __shared__ uint32_t wtot[NWAVE];
+    __shared__ uint2 wnn[NWAVE];
+    const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (j + TPB - 1) / TPB;
+    const int k0 = t * per, k1 = (k0 + per < j) ? k0 + per : j;
+    uint32_t bd = NONE, bi = NONE, cnt = 0;
+    for (int k = k0; k < k1; ++k) {
+        const uint32_t d2 = dist2(nodes[k], xq);
+        if (d2 < bd) {  // ascending k: strict < keeps the lowest index among equals
+            bd = d2;
+            bi = (uint32_t)k;
+        }
+        cnt += d2 < r2 ? 1u : 0u;
+    }
+    wave_min_key_idx(bd, bi);
+    uint32_t incl = cnt;  // inclusive prefix over the wave's lanes
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
+    if (lane == 63) wtot[wave] = incl;
+    if (lane == 0) wnn[wave] = make_uint2(bd, bi);
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < NWAVE; ++w) {
+        base += w < wave ? wtot[w] : 0u;
+        total += wtot[w];
+    }
+    uint32_t nd = NONE, ni = NONE;
+    if (lane < NWAVE) {
+        nd = wnn[lane].x;
+        ni = wnn[lane].y;
+    }
+    wave_min_key_idx(nd, ni);
+    uint32_t pos = base + incl - cnt;
+    for (int k = k0; k < k1; ++k)
+        if (dist2(nodes[k], xq) < r2) {
+            if (pos < (uint32_t)cap) out[2 + pos] = k;
+            ++pos;
+        }
+    if (t == 0) {
+        out[0] = (int32_t)ni;
+        out[1] = (int32_t)total;
+    }
+    __syncthreads();  // the index list is complete (and visible to this workgroup)
+    const int nseg = 1 + (int)(total < (uint32_t)cap ? total : (uint32_t)cap);
+    for (int s = wave; s < nseg; s += NWAVE) {
+        const uint32_t a = nodes[s == 0 ? (int)ni : out[2 + s - 1]];
+        int cells = 0;
+        const bool ok = los_wave(og, H, a, xq, lane, cells);
+        if (lane == 0) los[s] = (uint8_t)ok;
+    }
+}
+
 // r2norm on an integer radicand (rrt.py:24) exactly as the kernels evaluate it.
 __global__ void prim_sqrt_kernel(uint32_t lo, uint32_t count, double *out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

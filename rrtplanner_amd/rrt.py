@@ -7,6 +7,7 @@ attributes ``dist`` / ``cost`` (rrt.py:334-369) -- but its body is one call into
 (include/rrt_hip.h) instead of the Python loop.  The numpy ``Generator`` stays the source of
 randomness on the host, so the sample stream is the reference's bit for bit.
 
+A caller-supplied ``costfn`` keeps the loop on the host (``hostloop.py``) with the device answering its per-iteration questions.
 There is no CPU fallback for ``plan()``: without the HIP library or a GPU it raises.
 Tie policy: nearest node / goal connection pick the lowest index among
 equal distance / cost (== a stable argsort in rrt.py:154 and :317).
@@ -24,12 +25,42 @@ from .hostprep import INT64_MIN
 __all__ = ["r2norm", "random_point_og", "RRT", "RRTStandard", "RRTStar", "RRTStarInformed", "TreeDiGraph"]
 
 
+def _networkx_layout_ok() -> bool:
+    """The fast graph construction below writes networkx's private dictionaries (`_node`, `_adj` / `_succ`, `_pred`).  Check on
+    a scratch graph that they are laid out the way this file assumes (true for networkx 2.x and 3.x as tested; the reference pins
+    2.6.3): plain dicts, `_succ` the same object as `_adj`, add_node / add_edge filling them as dict-of-dict with ONE shared
+    attribute dict per edge.  Anything else (a future networkx) switches to the public add_node / add_edge calls."""
+    try:
+        g = nx.DiGraph()
+        g.add_node(7, pt=1)
+        g.add_edge(7, 8, dist=1.0, cost=2.0)
+        return (type(g._node) is dict and type(g._adj) is dict and type(g._pred) is dict and g._succ is g._adj and g._node[7] == {"pt": 1}
+                and g._adj[7][8] is g._pred[8][7] and g._adj[7][8] == {"dist": 1.0, "cost": 2.0} and g._adj[8] == {} and g._pred[7] == {})
+    except Exception:
+        return False
+
+
+_NX_FAST = _networkx_layout_ok()
+
+
+def _fill_graph_public(T, vgoal, points, parents, vcosts):
+    """build_graph of the reference call by call (rrt.py:357-369), through networkx's public interface only."""
+    T.add_node(vgoal, pt=points[vgoal])
+    for i, p in enumerate(points):
+        T.add_node(i, pt=p)
+    for child, parent in parents.items():
+        if parent is not None:
+            T.add_edge(parent, child, dist=r2norm(points[child] - points[parent]), cost=vcosts[child])
+
+
 def _fill_graph(T, vgoal, points, parents, vcosts):
     """Fill the node / adjacency dictionaries of DiGraph `T` like build_graph of the reference (rrt.py:357-369): node order
     [vgoal, 0, 1, ...], one edge per tree link in the order of `parents`, attributes `pt` (int64 row view), `dist` (float),
     `cost` (np.float64).  The dictionaries are written directly (same dict-of-dict layout `add_node` / `add_edge` produce, one
     shared attribute dict per edge in `_succ` and `_pred`), ~3x faster than 100 000 add_node / add_edge calls;
     tests/test_host_logic.py compares it with the call-by-call construction."""
+    if not _NX_FAST:
+        return _fill_graph_public(T, vgoal, points, parents, vcosts)
     rows = len(points)
     order = [vgoal] + [i for i in range(rows) if i != vgoal] if 0 <= vgoal < rows else [vgoal] + list(range(rows))
     pts = list(points)  # row views, like `for i, p in enumerate(points)`
@@ -65,6 +96,14 @@ class TreeDiGraph(nx.DiGraph):
     @classmethod
     def from_arrays(cls, vgoal, points, parent, vcosts):
         """points (rows, 2) int64, parent (live,) int (-1 for the root), vcosts (rows,) float64; rows >= live"""
+        if not _NX_FAST:  # unknown networkx layout: an ordinary, eagerly built DiGraph (same content, see _networkx_layout_ok)
+            T = nx.DiGraph()
+            parents = {0: None}
+            for child, p in enumerate(np.asarray(parent).tolist()):
+                if child > 0:
+                    parents[child] = p
+            _fill_graph_public(T, int(vgoal), points, parents, vcosts)
+            return T
         T = cls()
         T.__dict__["_lazy"] = (int(vgoal), points, parent, vcosts)
         return T
@@ -268,12 +307,6 @@ class RRT(object):
 
     def _run(self, alg: int, xstart, xgoal, r_rewire=None, r_goal=None, logs=False, rewire=False):
         """Drive one query through the C ABI.  Returns the ResultArrays (+ ellipse log inputs)."""
-        if self._custom_cost:
-            raise NotImplementedError(
-                "rrtplanner_amd runs the expansion loop on the GPU with the reference's default cost "
-                "(vcosts[v] + r2norm(points[v] - x), rrt.py:72-78); an arbitrary Python costfn cannot be "
-                "lowered to the device and there is no CPU fallback."
-            )
         xs = hostprep.as_int_point(xstart, "xstart")
         xg = hostprep.as_int_point(xgoal, "xgoal")
         W, H = np.asarray(self.og).shape
@@ -351,7 +384,38 @@ class RRT(object):
         _fill_graph(T, vgoal, points, parents, vcosts)
         return T
 
+    def _plan_costfn(self, alg, xstart, xgoal):
+        """plan() with a caller-supplied cost function (rrt.py:55, :70-80): the callable stays in Python, so the loop runs on the
+        host (rrtplanner_amd/hostloop.py, the reference's statements incl. its real rewire block) and takes near()[0],
+        within() and every line of sight from the device, once per iteration (rrt_tree_query).  Not accelerated like the
+        default cost, but the same device primitives; there is no CPU path."""
+        from . import hostloop
+
+        xs = hostprep.as_int_point(xstart, "xstart")
+        xg = hostprep.as_int_point(xgoal, "xgoal")
+        W, H = np.asarray(self.og).shape
+        for p, name in ((xs, "xstart"), (xg, "xgoal")):
+            if not (0 <= p[0] < W and 0 <= p[1] < H):
+                raise ValueError(f"{name}={p.tolist()} lies outside the {W}x{H} occupancy grid")
+        prov = getattr(self, "_costfn_provider", None)  # (tests: a stand-in for the device primitives)
+        own = prov is None
+        if own:
+            prov = hostloop.DeviceProvider(self._device(), int(self.n))
+        bar = tqdm(total=self.n) if self.pbar else None
+        try:
+            vgoal, points, parents, vcosts = hostloop.plan_with_costfn(self, alg, xs, xg, prov, bar)
+        finally:
+            if bar is not None:
+                bar.close()
+            if own:
+                prov.close()
+        return self.build_graph(vgoal, points, parents, vcosts), vgoal
+
     def _plan(self, alg, xstart, xgoal, **kw):
+        if self._custom_cost:
+            if kw.get("rewire"):
+                raise ValueError('rewire="correct" is defined for the default cost only; a custom costfn runs the reference\'s own rewire block')
+            return None, self._plan_costfn(alg, xstart, xgoal)
         bar = tqdm(total=self.n) if self.pbar else None
         try:
             res = self._run(alg, xstart, xgoal, **kw)
@@ -431,7 +495,8 @@ class RRTStarInformed(RRT):
 
     def plan(self, xstart: np.ndarray, xgoal: np.ndarray):
         res, out = self._plan(_ffi.ALG_INFORMED, xstart, xgoal, r_rewire=self.r_rewire, r_goal=self.r_goal, rewire=_rewire_mode(self.rewire))
-        self._record_ellipses(res)
+        if res is not None:  # (a custom costfn records self.ellipses in its host loop, rrt.py:701)
+            self._record_ellipses(res)
         return out
 
     # ---- the sampler's helpers of the reference's public surface (rrt.py:579-651), on the host.  plan() draws the same

@@ -153,7 +153,11 @@ def record_plan(cap, planner, xs, xg, arrays, prefix, meta, full_graph):
     arrays[prefix + "parent"] = par
     arrays[prefix + "parent_order"] = np.asarray([c for c in parents.keys()], dtype=np.int32)
     arrays[prefix + "nearest_log"] = np.asarray(cap.nearest, dtype=np.int32)
-    path = planner.route2gv(T, gv)
+    try:
+        path = planner.route2gv(T, gv)
+    except Exception as e:  # (custom cost functions only: the reference's rewire block can cut the goal off the root)
+        meta["route_raises"] = type(e).__name__
+        path = []
     arrays[prefix + "path"] = np.asarray([int(v) for v in path], dtype=np.int32)
     meta["vgoal"] = int(gv)
     meta["rows"] = int(rows)

@@ -125,16 +125,55 @@ class OracleCtx:
         return st
 
 
-def make_planner(mod, meta, og, device_ctx=None):
+def make_planner(mod, meta, og, device_ctx=None, costfn=None):
     """Planner of `mod` (rrtplanner_amd.rrt) for a golden manifest entry."""
     alg, n, seed = meta["alg"], meta["n"], meta["seed"]
     if alg == 0:
-        p = mod.RRTStandard(og, n, pbar=False, seed=seed)
+        p = mod.RRTStandard(og, n, costfn=costfn, pbar=False, seed=seed)
     elif alg == 1:
-        p = mod.RRTStar(og, n, meta["r_rewire"], pbar=False, seed=seed)
+        p = mod.RRTStar(og, n, meta["r_rewire"], costfn=costfn, pbar=False, seed=seed)
     else:
-        p = mod.RRTStarInformed(og, n, meta["r_rewire"], meta["r_goal"], pbar=False, seed=seed)
+        p = mod.RRTStarInformed(og, n, meta["r_rewire"], meta["r_goal"], costfn=costfn, pbar=False, seed=seed)
     return p
+
+
+class NumpyProvider:
+    """Stand-in for the device primitives of a host-driven planner (rrtplanner_amd/hostloop.py: rrt_tree_query /
+    rrt_prim_collisionfree), so that the loop itself can be checked against the reference's goldens without a GPU.  numpy for
+    near()[0] / within(), the C oracle's line walk for collisionfree."""
+
+    def __init__(self, og8):
+        self.og8 = np.ascontiguousarray(og8, dtype=np.uint8)
+        self.pts = np.zeros((0, 2), dtype=np.int64)
+        self.j = 0
+        self.queries = 0
+
+    def reset(self):
+        self.pts = np.zeros((1024, 2), dtype=np.int64)
+        self.j = 0
+
+    def append(self, x, y):
+        if self.j == self.pts.shape[0]:
+            self.pts = np.concatenate([self.pts, np.zeros_like(self.pts)])
+        self.pts[self.j] = (x, y)
+        self.j += 1
+        return self.j - 1
+
+    def query(self, x, y, r2):
+        self.queries += 1
+        p = self.pts[:self.j]
+        d = p - np.array((x, y))
+        d2 = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]
+        nearest = int(np.argmin(d2))  # first minimum: lowest index among equal distance
+        idx = np.flatnonzero(d2 < r2).astype(np.int32)
+        los = np.array([oracle.collisionfree(self.og8, p[k], (x, y))[0] for k in idx], dtype=bool)
+        return nearest, idx, bool(oracle.collisionfree(self.og8, p[nearest], (x, y))[0]), los
+
+    def collisionfree_many(self, ab):
+        return np.array([oracle.collisionfree(self.og8, s[:2], s[2:])[0] for s in np.asarray(ab).reshape(-1, 4)], dtype=bool)
+
+    def close(self):
+        pass
 
 
 def use_oracle(planner):
@@ -181,7 +220,15 @@ def check_plan_against_golden(G, meta, planner, T, gv, check_graph=True):
     live = got_parent >= 0
     assert np.allclose(got_cost[live], vcost[live], rtol=0, atol=1e-6)
     assert np.array_equal(got_cost[live], vcost[live]), "edge costs are not bit-identical"
-    path = planner.route2gv(T, gv)
+    if meta.get("route_raises"):  # (custom cost functions: the reference's rewire block can cut the goal off the root)
+        import networkx as nx
+        import pytest
+
+        with pytest.raises(getattr(nx, meta["route_raises"])):
+            planner.route2gv(T, gv)
+        path = []
+    else:
+        path = planner.route2gv(T, gv)
     assert [int(v) for v in path] == G.arr(cid, "path").tolist()
     assert rng_state_tuple(planner.rand_gen) == meta["rng_state"], "generator state after plan() differs"
     if check_graph and G.has(cid, "node_order"):

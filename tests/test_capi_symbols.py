@@ -46,3 +46,18 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_integration_stub_structs_match_the_binding():
+    """The ctypes structs in INTEGRATION.md's stub have the layout of the binding's (a field appended to rrt_query / rrt_result
+    without the stub following would make rrt_plan write past the stub's struct).  The stub itself runs in the GPU suite."""
+    import ctypes as C
+    import re
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    ns = {}
+    exec(compile(code.replace('C.CDLL("librrt_hip.so")', f"C.CDLL({_ffi.LIB_PATH!r})"), "INTEGRATION.md", "exec"), ns)
+    for stub, ours in ((ns["_Query"], _ffi.Query), (ns["_Result"], _ffi.Result)):
+        assert C.sizeof(stub) == C.sizeof(ours)
+        assert [(n, getattr(stub, n).offset) for n, _ in stub._fields_] == [(n, getattr(ours, n).offset) for n, _ in ours._fields_]

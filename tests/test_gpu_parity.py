@@ -464,6 +464,41 @@ def test_bench_as_a_rank_and_as_its_own_launcher():
     assert plain["host_gap_ms"] < 0.25, plain  # the step is the kernel: what the host adds stays below a quarter millisecond
 
 
+def test_integration_stub_runs():
+    """INTEGRATION.md shows the ctypes stub a maintainer of the reference would add to rrtplanner/rrt.py.  Execute that very
+    block: bind its _device_plan onto a minimal class that has what the reference's planner has (og, free, n, rand_gen,
+    r_rewire, build_graph) and compare with rrtplanner_amd.RRTStar / RRTStandard -- same graph, same goal vertex."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1)
+    assert "_device_plan" in code and 'C.CDLL("librrt_hip.so")' in code
+    ns = {}
+    exec(compile(code.replace('C.CDLL("librrt_hip.so")', f"C.CDLL({_ffi.LIB_PATH!r})"), "INTEGRATION.md", "exec"), ns)
+
+    class Minimal:  # the state the reference's RRT.__init__ leaves behind (rrt.py:59-85)
+        def __init__(self, og, n, r_rewire, seed):
+            self.og, self.n, self.r_rewire = og, n, r_rewire
+            self.free = np.argwhere(og == 0)
+            self.rand_gen = np.random.default_rng(seed)
+
+        build_graph = amd.RRT.build_graph
+
+    og = perlin_occupancygrid(300, 300, seed=5)
+    xs, xg = random_connected_pair(og, np.random.default_rng(3))
+    for alg, cls, kw in ((1, amd.RRTStar, dict(r_rewire=40.5)), (0, amd.RRTStandard, {})):
+        m = Minimal(og, 4000, kw.get("r_rewire", 0), seed=9)
+        Ts, gs = ns["_device_plan"](m, alg, xs, xg)
+        p = cls(og, 4000, pbar=False, seed=9, **kw)
+        T, g = p.plan(xs, xg)
+        assert gs == g and list(Ts.nodes) == list(T.nodes) and list(Ts.edges) == list(T.edges)
+        assert [d["cost"] for _, _, d in Ts.edges(data=True)] == [d["cost"] for _, _, d in T.edges(data=True)]
+        assert all(np.array_equal(Ts.nodes[v]["pt"], T.nodes[v]["pt"]) for v in list(T.nodes)[:500])
+        assert m.rand_gen.bit_generator.state == p.rand_gen.bit_generator.state
+        ns["_lib"].rrt_ctx_destroy(m._ctx)
+
+
 def test_plan_batch_one_shot(gpu_ctx):
     """rrt_plan_batch (the one-call form of the batch API): 6 mixed RRTStandard / RRTStar queries of different n."""
     og = perlin_occupancygrid(512, 512, seed=2)

@@ -100,8 +100,12 @@ def test_plan_argument_validation_without_device():
         p._run(0, np.array([0, 0]), np.array([10, 3]))
     with pytest.raises(ValueError):
         p._run(0, np.array([0.5, 0]), np.array([1, 3]))
-    with pytest.raises(NotImplementedError):
-        amd.RRTStandard(og, 5, costfn=lambda *a: 0.0, pbar=False)._run(0, np.array([0, 0]), np.array([1, 1]))
+    # a custom cost function keeps the loop on the host (hostloop.py) but validates the same way, and never runs without a device
+    q = amd.RRTStandard(og, 5, costfn=lambda *a: 0.0, pbar=False)
+    with pytest.raises(ValueError):
+        q.plan(np.array([0, 0]), np.array([10, 3]))
+    with pytest.raises(amd._ffi.RRTError):  # no GPU in this test run: no silent CPU path
+        q.plan(np.array([0, 0]), np.array([1, 1]))
 
 
 def test_sharding_helpers():
@@ -266,3 +270,25 @@ def test_host_go2goal_helper_follows_the_reference_contract():
     og[10, :] = 1
     vgoal, _, _, pts3, vc3 = p.go2goal(vcosts, points, np.array([15, 1]), 4, defaultdict(list), {0: None})
     assert vgoal == 0 and pts3.shape == (4, 2) and vc3.shape == (4,)
+
+
+def test_unknown_networkx_layout_falls_back_to_public_calls(monkeypatch):
+    """TreeDiGraph / the fast build_graph write networkx's private dictionaries; when a scratch graph does not look
+    the way they assume, both go through add_node / add_edge and give the same graph."""
+    import networkx as nx
+
+    assert amd._networkx_layout_ok() and amd._NX_FAST  # the networkx of this image (3.x); the reference pins 2.6.3
+    points = np.array([[1, 1], [4, 5], [7, 1], [9, 9], [amd.INT64_MIN, amd.INT64_MIN]], dtype=np.int64)
+    vcosts = np.array([0.0, 5.0, 6.0, 13.0, np.inf])
+    parent = np.array([-1, 0, 0, 1])
+    fast = amd.TreeDiGraph.from_arrays(3, points, parent, vcosts)
+    monkeypatch.setattr(amd, "_NX_FAST", False)
+    slow = amd.TreeDiGraph.from_arrays(3, points, parent, vcosts)
+    assert type(slow) is nx.DiGraph and isinstance(fast, amd.TreeDiGraph)
+    assert list(slow.nodes) == list(fast.nodes) == [3, 0, 1, 2, 4]
+    assert list(slow.edges(data=True)) == list(fast.edges(data=True))
+    assert all(np.array_equal(slow.nodes[v]["pt"], fast.nodes[v]["pt"]) for v in fast.nodes)
+    p = amd.RRTStandard(np.zeros((10, 10), dtype=int), 4, pbar=False)
+    assert p.route2gv(slow, 3) == p.route2gv(fast, 3) == [0, 1, 3]
+    g = p.build_graph(3, points, {0: None, 1: 0, 2: 0, 3: 1}, vcosts)  # the public method, also on the slow path now
+    assert list(g.edges(data=True)) == list(fast.edges(data=True))
