@@ -10,7 +10,12 @@
  * rrt_last_error_string() describes the last failure.
  *
  * Threading: a ctx (and the batches made from it) is used by one host thread at a
- * time; distinct ctxs are independent (each owns a HIP stream).
+ * time; distinct ctxs may be used by distinct host threads at the same time (each owns
+ * a HIP stream).  They share the device: a launch sizes its teams of compute units by
+ * what the launches in flight of the same process have left free (rrt_batch_team_info),
+ * so concurrent batches slow each other down but never wait for CUs they cannot get.
+ * Kernels of OTHER processes on the same GPU are not seen by that registry; there the
+ * bounded hand-off wait (0.5 s, then one CU per query) remains the safety net.
  */
 #ifndef RRT_HIP_H
 #define RRT_HIP_H
@@ -143,6 +148,12 @@ int rrt_batch_sync(rrt_batch *b);
 /* CUs working on each query (the team size chosen at rrt_batch_create) and how often a team hand-off timed out: such a launch
  * is continued once with one CU per query, the next launch uses the team again */
 int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fallbacks);
+/* out = {workers per query the batch was created with (the shape on an otherwise idle device), workers per query of the last
+ * launch, launches continued with one CU per query after a hand-off timed out, launches that ran a SMALLER team because other
+ * launches of this process held compute units of the device}.  The members of a team wait for each other, so all of them must be
+ * resident at once: every launch claims its compute units in a per-device registry of the library and, when they are not all
+ * free, takes the largest team that fits next to the launches in flight (rrt_batch_sync returns the claim). */
+int rrt_batch_team_info(rrt_batch *b, int32_t out[4]);
 /* 1 if the last launch ran the pipelined team kernel (one more CU per query, which only commits) */
 int rrt_batch_pipelined(rrt_batch *b, int32_t *pipelined);
 /* name of the expansion kernel the last launch ran (the one before it, for a batch not launched yet: the one it would run),

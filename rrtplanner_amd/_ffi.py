@@ -54,7 +54,7 @@ SYMBOLS = (
     "rrt_grid_generation", "rrt_ctx_sync",
     "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_comm_allreduce_f64", "rrt_gather", "rrt_gather_fetch",
     "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
-    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_pipelined", "rrt_batch_kernel_name", "rrt_batch_elapsed_ms",
+    "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_team_info", "rrt_batch_pipelined", "rrt_batch_kernel_name", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
     "rrt_plan", "rrt_plan_resume", "rrt_plan_batch",
     "rrt_tree_create", "rrt_tree_destroy", "rrt_tree_reset", "rrt_tree_append", "rrt_tree_query",
@@ -130,6 +130,7 @@ def lib():
             "rrt_batch_launch": ([vp], C.c_int),
             "rrt_batch_sync": ([vp], C.c_int),
             "rrt_batch_team": ([vp, C.POINTER(i32), C.POINTER(i32)], C.c_int),
+            "rrt_batch_team_info": ([vp, C.POINTER(i32 * 4)], C.c_int),
             "rrt_batch_pipelined": ([vp, C.POINTER(i32)], C.c_int),
             "rrt_batch_kernel_name": ([vp, C.c_char_p, i32], C.c_int),
             "rrt_batch_elapsed_ms": ([vp, C.POINTER(C.c_float)], C.c_int),
@@ -466,6 +467,13 @@ class Batch:
         g, f = C.c_int32(0), C.c_int32(0)
         _check(self.ctx.handle, lib().rrt_batch_team(self._h, C.byref(g), C.byref(f)))
         return g.value, f.value
+
+    def team_info(self):
+        """dict: workers per query at creation / of the last launch, hand-off timeouts, launches that ran a smaller team because
+        other launches held compute units of the device"""
+        out = (C.c_int32 * 4)()
+        _check(self.ctx.handle, lib().rrt_batch_team_info(self._h, C.byref(out)))
+        return dict(created=out[0], last=out[1], timeouts=out[2], shrunk=out[3])
 
     def pipelined(self):
         """True if the last launch ran the pipelined team kernel"""

@@ -91,6 +91,9 @@ struct rrt_batch {
     bool last_inf = false;      // the last launch ran the Informed instantiation
     int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
     int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
+    int32_t team_want = TEAM_MAX;  // the caller's cap on the team size
+    int32_t claimed_cus = 0;    // compute units this batch's launch in flight holds in the device's registry (0: nothing in flight)
+    int32_t shrunk = 0;         // launches that ran a smaller team than the batch was created with because other launches held CUs
     unsigned char *d_team = nullptr;  // [Q][TEAM_BYTES] sync words, state, exchanged records; zeroed before every launch
     QDesc *d_desc = nullptr;
     PinnedDescs h_desc;  // page-locked
@@ -413,6 +416,30 @@ static int64_t cell_records_needed(int W, int H, int n) {
     return best;
 }
 
+// Compute units that launches in flight have claimed, per device (every batch of this process: all contexts, all host threads).
+// A team kernel's members wait for each other, so they must all be resident at once: a launch looks here and takes the largest
+// team whose workgroups fit NEXT TO what is in flight (one CU per query if nothing else does); rrt_batch_sync gives the claim back.
+namespace {
+std::mutex g_cu_mutex;
+std::vector<int> g_cu_claimed;  // [device]
+int cu_claim(int device, int num_cu, int want_cus, int min_cus) {
+    // claims `want_cus` if that many are free, else nothing (returns the free count, negative-free as 0, through *the caller's retry*)
+    std::lock_guard<std::mutex> lock(g_cu_mutex);
+    if ((int)g_cu_claimed.size() <= device) g_cu_claimed.resize((size_t)device + 1, 0);
+    const int free_cus = num_cu - g_cu_claimed[(size_t)device];
+    if (want_cus <= free_cus || want_cus <= min_cus) {
+        g_cu_claimed[(size_t)device] += want_cus;
+        return -1;  // granted
+    }
+    return free_cus < 0 ? 0 : free_cus;
+}
+void cu_release(int device, int cus) {
+    if (cus <= 0) return;
+    std::lock_guard<std::mutex> lock(g_cu_mutex);
+    if ((int)g_cu_claimed.size() > device) g_cu_claimed[(size_t)device] -= cus;
+}
+}  // namespace
+
 extern "C" int rrt_batch_destroy(rrt_batch *b) {
     if (!b) return RRT_OK;
     (void)hipSetDevice(b->ctx->device);
@@ -425,11 +452,50 @@ extern "C" int rrt_batch_destroy(rrt_batch *b) {
         if (p) (void)hipFree(p);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
+    cu_release(b->ctx->device, b->claimed_cus);
+    b->claimed_cus = 0;
     if (b->ctx->single == b) b->ctx->single = nullptr;
     if (b->ctx->gather_owner == b) b->ctx->gather_owner = nullptr;
     b->h_desc.release();
     delete b;
     return RRT_OK;
+}
+
+// The team shape for Q queries on `cus` compute units: the largest team (CUs per query) with every member of every team resident
+// at once.  Blocks are dealt round-robin to the 8 XCDs, so block = member * stride + query with stride = 0 (mod 8) keeps a team of
+// up to 16 on one XCD (one L2); larger teams use stride = 4 / 2 (mod 8): two / four XCDs with 16 members each (speed only).
+// A pipelined team (g workers + a committer) beats an unpipelined one of twice its size (config 2: 8+1 CUs 24.7 ms vs 16 CUs
+// 27.3 ms; config 4's share: 3+1 CUs vs 4 CUs, profiles/r02_experiments.md).
+struct TeamShape {
+    int team = 1, qpad = 0;
+    bool pipe = false;
+    int cus() const { return team > 1 ? qpad * (team + (pipe ? 1 : 0)) : 0; }  // workgroups that must be resident together
+};
+static TeamShape pick_team(int Q, int want, bool allow_pipe, int cus) {
+    TeamShape t;
+    t.qpad = (Q + 7) & ~7;
+    auto stride_of = [&](int g) {
+        const int step = g <= 16 ? 8 : (g == 32 ? 4 : 2);
+        int stride = ((Q + step - 1) / step) * step;
+        if (g == 32 && stride % 8 == 0) stride += 4;
+        if (g == 64 && stride % 4 == 0) stride += 2;
+        return stride;
+    };
+    for (int g : {2, 4, 8, 16, 32, 64})
+        if (g <= want && stride_of(g) * g <= cus) {
+            t.team = g;
+            t.qpad = stride_of(g);
+        }
+    int pipe_g = 0;
+    if (allow_pipe)
+        for (int g : {2, 3, 4, 8, 16, 32, 64})
+            if (g <= want && stride_of(g) * (g + 1) <= cus) pipe_g = g;
+    if (pipe_g != 0 && t.team <= 2 * pipe_g) {
+        t.team = pipe_g;
+        t.qpad = stride_of(pipe_g);
+        t.pipe = true;
+    }
+    return t;
 }
 
 extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t flags, rrt_batch **out) {
@@ -457,39 +523,16 @@ extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t
     b->use_block = !(flags & (RRT_FLAG_SERIAL | RRT_FLAG_REWIRE | RRT_FLAG_DUBINS));
     b->dub_block = (flags & RRT_FLAG_DUBINS) && !(flags & RRT_FLAG_SERIAL);
     if (b->use_block && !(flags & RRT_FLAG_NOTEAM)) {
-        // the largest team (CUs per query) with every member of every team resident at once.  Blocks are dealt round-robin
-        // to the 8 XCDs, so block = member * stride + query with stride = 0 (mod 8) keeps a team of up to 16 on one XCD (one
-        // L2); larger teams use stride = 4 / 2 (mod 8): two / four XCDs with 16 members each.  Placement is speed only.
         int want = (int)((flags >> 8) & 0x7fu);
         if (want == 0) want = TEAM_MAX;
 #ifdef RRT_STAMPS
         if (const char *e = getenv("RRT_TEAM")) want = atoi(e);  // diagnostic build only: cap the team size
 #endif
-        b->team = 1;
-        b->team_qpad = (Q + 7) & ~7;
-        auto stride_of = [&](int g) {
-            const int step = g <= 16 ? 8 : (g == 32 ? 4 : 2);
-            int stride = ((Q + step - 1) / step) * step;
-            if (g == 32 && stride % 8 == 0) stride += 4;
-            if (g == 64 && stride % 4 == 0) stride += 2;
-            return stride;
-        };
-        for (int g : {2, 4, 8, 16, 32, 64})
-            if (g <= want && stride_of(g) * g <= ctx->num_cu) {
-                b->team = g;
-                b->team_qpad = stride_of(g);
-            }
-        // pipelined teams: g workers and a committer (g + 1 CUs).  A pipelined team beats an unpipelined one of twice its size
-        // (config 2: 8+1 CUs 24.7 ms vs 16 CUs 27.3 ms; config 4's share: 3+1 CUs vs 4 CUs, profiles/r02_experiments.md)
-        int pipe_g = 0;
-        if (!(flags & RRT_FLAG_NOPIPE))
-            for (int g : {2, 3, 4, 8, 16, 32, 64})
-                if (g <= want && stride_of(g) * (g + 1) <= ctx->num_cu) pipe_g = g;
-        if (pipe_g != 0 && b->team <= 2 * pipe_g) {
-            b->team = pipe_g;
-            b->team_qpad = stride_of(pipe_g);
-            b->pipe_team = true;
-        }
+        b->team_want = want;
+        const TeamShape ts = pick_team(Q, want, !(flags & RRT_FLAG_NOPIPE), ctx->num_cu);  // the shape on an otherwise idle device
+        b->team = ts.team;
+        b->team_qpad = ts.qpad;
+        b->pipe_team = ts.pipe;
     }
     b->spill_stride = chunks * CHUNK * (b->team + 1);  // per member (and a pipelined team's committer): 256 parked entries per wave and node chunk; also go2goal's cost array
     {   // block kernel LDS: [node cache | cell fill counts 16 KiB | the waves' parked-entry lists 64 KiB (teams of up to 4 workers and
@@ -762,10 +805,10 @@ static const void *block_kernel_of(int team, bool pipe, bool inf) { return reint
 static size_t block_kernel_static_lds(int team) {
     hipFuncAttributes a{};
     size_t worst = 0;
-    for (int g : {team, 1})
+    for (int g : {1, 2, 3, 4, 8, 16, 32, 64})  // (a launch may run any smaller team when other launches hold compute units)
         for (bool pipe : {false, true})
             for (bool inf : {false, true}) {
-                if (pipe && g < 2) continue;
+                if (g > team || (pipe && g < 2)) continue;
                 if (!pipe && g == 3) continue;  // (three workers exist only as a pipelined team)
                 if (hipFuncGetAttributes(&a, block_kernel_of(g, pipe, inf)) != hipSuccess) return 16384;
                 worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
@@ -789,13 +832,42 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     if (b->use_block) {
         // after a hand-off timed out this one launch continues the batch with one CU per query; the team size the batch was
         // created with stays and the next launch uses it again
-        const int team = b->one_cu_once ? 1 : b->team;
+        int team = b->one_cu_once ? 1 : b->team;
+        bool pipe_shape = b->pipe_team;
         b->one_cu_once = false;
+        cu_release(ctx->device, b->claimed_cus);  // (a launch that was never synchronised)
+        b->claimed_cus = 0;
+        if (team > 1) {
+            // every member of every team must be resident at once: claim the CUs, or take the largest team that fits next to the
+            // launches in flight on this device (other batches, other contexts, other host threads of this process)
+            TeamShape ts;
+            ts.team = team;
+            ts.qpad = b->team_qpad;
+            ts.pipe = pipe_shape;
+            for (;;) {
+                const int free_cus = cu_claim(ctx->device, ctx->num_cu, ts.cus(), 0);
+                if (free_cus < 0) break;  // granted
+                TeamShape smaller = pick_team(b->Q, b->team_want < ts.team ? b->team_want : ts.team, pipe_shape, free_cus);
+                if (smaller.team >= ts.team && smaller.pipe == ts.pipe) smaller.team = 1;  // (the registry changed in between: do not loop)
+                ts = smaller;
+                if (ts.team <= 1) break;
+            }
+            if (ts.team != team) b->shrunk += 1;
+            team = ts.team;
+            pipe_shape = ts.pipe;
+            v.team_qpad = ts.qpad;
+            b->claimed_cus = team > 1 ? ts.cus() : 0;
+        }
+        if (team <= 1) {  // one CU per query needs no co-residency, but its workgroups occupy CUs all the same
+            team = 1;
+            b->claimed_cus = b->Q < ctx->num_cu ? b->Q : ctx->num_cu;
+            (void)cu_claim(ctx->device, ctx->num_cu, b->claimed_cus, b->claimed_cus);
+        }
         const bool lists = team <= 4;  // one wave per sample: its parked entries stay in LDS
         v.lds_chunks = lists ? b->blk_lds_chunks16 : b->blk_lds_chunks;
         const size_t blk_lds_bytes = (size_t)MAX_CELLS * sizeof(uint32_t) + (lists ? BLOCK_LIST_LDS_BYTES : 0) + (size_t)v.lds_chunks * CHUNK * sizeof(uint32_t);
         // a two-deep pipeline of super-blocks (one more workgroup per team, which only commits) for teams of 8 and more
-        bool pipe = team > 1 && b->pipe_team;
+        bool pipe = team > 1 && pipe_shape;
 #ifdef RRT_STAMPS
         if (const char *e = getenv("RRT_PIPE")) pipe = pipe && atoi(e) != 0;  // diagnostic build only
 #endif
@@ -809,13 +881,16 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         if (team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
-        const dim3 tg(team > 1 ? (unsigned)(b->team_qpad * (team + (pipe ? 1 : 0))) : (unsigned)b->Q);
+        const dim3 tg(team > 1 ? (unsigned)(v.team_qpad * (team + (pipe ? 1 : 0))) : (unsigned)b->Q);
         hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf), tg, dim3(TPB), blk_lds_bytes, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;
         return RRT_OK;
     }
+    cu_release(ctx->device, b->claimed_cus);
+    b->claimed_cus = b->Q < ctx->num_cu ? b->Q : ctx->num_cu;  // one workgroup per query: no co-residency needed, the CUs are busy all the same
+    (void)cu_claim(ctx->device, ctx->num_cu, b->claimed_cus, b->claimed_cus);
     if (b->dub_block) {
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
@@ -853,6 +928,8 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(b->h_desc.data(), b->d_desc, (size_t)b->Q * sizeof(QDesc), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, wait_stream_spin(ctx->stream));
+    cu_release(ctx->device, b->claimed_cus);  // the launch is over: its compute units are free for the launches of other batches
+    b->claimed_cus = 0;
     // A team whose members were not resident together stops at a block boundary with a consistent tree (ST_TEAM_FAIL, a
     // bounded wait expired).  Teams are only an optimisation: the batch continues from there with one CU per query.
     bool team_fail = false;
@@ -872,6 +949,8 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
         if (rc != RRT_OK) return rc;
         HIPCHK(ctx, hipMemcpyAsync(b->h_desc.data(), b->d_desc, (size_t)b->Q * sizeof(QDesc), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, wait_stream_spin(ctx->stream));
+        cu_release(ctx->device, b->claimed_cus);
+        b->claimed_cus = 0;
     }
     return RRT_OK;
 }
@@ -880,6 +959,15 @@ extern "C" int rrt_batch_team(rrt_batch *b, int32_t *cus_per_query, int32_t *fal
     if (!b || !cus_per_query) return fail(nullptr, RRT_E_ARG, "rrt_batch_team: NULL");
     *cus_per_query = b->use_block ? b->team : 1;
     if (fallbacks) *fallbacks = b->team_fallbacks;
+    return RRT_OK;
+}
+
+extern "C" int rrt_batch_team_info(rrt_batch *b, int32_t out[4]) {
+    if (!b || !out) return fail(nullptr, RRT_E_ARG, "rrt_batch_team_info: NULL");
+    out[0] = b->use_block ? b->team : 1;
+    out[1] = b->use_block ? (b->last_team > 0 ? b->last_team : b->team) : 1;
+    out[2] = b->team_fallbacks;
+    out[3] = b->shrunk;
     return RRT_OK;
 }
 

@@ -464,6 +464,79 @@ def test_bench_as_a_rank_and_as_its_own_launcher():
     assert plain["host_gap_ms"] < 0.25, plain  # the step is the kernel: what the host adds stays below a quarter millisecond
 
 
+def test_two_contexts_share_the_device_without_timeouts():
+    """two planners in one process (two contexts, two host threads) used to size their teams as if each had the whole
+    device, and each then waited 0.5 s for members that could not be resident.  Now a launch claims its compute units in the
+    library's per-device registry and takes the largest team that fits next to the launches in flight: both batches finish with
+    the oracle's trees, no hand-off times out, the later launch of a pair runs a smaller team, and alone again a batch gets its
+    full team back."""
+    import threading
+    import time
+
+    og = perlin_occupancygrid(1024, 1024, seed=1)
+    og8 = oracle.og_u8(og)
+    free = np.argwhere(og8 == 0)
+    Q, n = 8, 12000
+    r2 = hostprep.radius_threshold(64)
+    qs = _bench_config4_queries(og, free, 2 * Q, n)
+    refs = [oracle.plan(og8, n, 1, xs, xg, s, r2_rewire=r2, logs=False) for xs, xg, s in qs]
+    ctxs = [_ffi.Context(0), _ffi.Context(0)]
+    batches, keep = [], []
+    for c, ctx in enumerate(ctxs):
+        ctx.set_grid(og8)
+        b = _ffi.Batch(ctx, Q, n)
+        for q in range(Q):
+            xs, xg, s = qs[c * Q + q]
+            qu, k = _ffi.make_query(1, n, xs, xg, s, r2_rewire=r2)
+            keep.append(k)
+            b.set_query(q, qu)
+        batches.append(b)
+    assert batches[0].team_info()["created"] == 16 and batches[1].team_info()["created"] == 16  # 8 x (16 + 1) = 136 of 256 CUs each
+    gate = threading.Barrier(2)
+    errors, wall = [], [0.0, 0.0]
+
+    def run(c):
+        try:
+            b = batches[c]
+            for rep in range(4):
+                b.rearm()
+                gate.wait()
+                t0 = time.perf_counter()
+                b.launch()
+                b.sync()
+                wall[c] = max(wall[c], time.perf_counter() - t0)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            gate.abort()
+
+    th = [threading.Thread(target=run, args=(c,)) for c in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    info = [b.team_info() for b in batches]
+    assert info[0]["timeouts"] == 0 and info[1]["timeouts"] == 0, info
+    assert info[0]["shrunk"] + info[1]["shrunk"] >= 1, info  # the two 136-CU shapes do not fit 256 CUs together
+    assert max(wall) < 0.3, wall  # nowhere near a 0.5 s hand-off time-out
+    for c, b in enumerate(batches):
+        for q in range(Q):
+            st, ro = refs[c * Q + q]
+            res = b.get_result(q)
+            live = ro.j + (1 if ro.found else 0)
+            assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal, (c, q)
+            assert np.array_equal(res.parent[:live], ro.parent[:live]) and np.array_equal(res.vcost[:live], ro.vcost[:live]), (c, q)
+    before = batches[0].team_info()["shrunk"]
+    batches[0].rearm()
+    batches[0].launch()
+    batches[0].sync()  # alone on the device: the full team again
+    assert batches[0].team_info() == dict(created=16, last=16, timeouts=0, shrunk=before)
+    for b in batches:
+        b.close()
+    for ctx in ctxs:
+        ctx.close()
+
+
 def test_integration_stub_runs():
     """INTEGRATION.md shows the ctypes stub a maintainer of the reference would add to rrtplanner/rrt.py.  Execute that very
     block: bind its _device_plan onto a minimal class that has what the reference's planner has (og, free, n, rand_gen,
@@ -855,11 +928,23 @@ def test_missing_grid_and_bad_arguments_fail_loudly():
     ctx.close()
 
 
-def test_custom_costfn_is_rejected_not_emulated():
+def test_custom_costfn_runs_on_the_device_primitives():
+    """A custom cost function no longer raises: the loop stays in Python, the device answers its questions (rrt_tree_query);
+    tests/test_costfn.py compares 40 such plans with the real reference.  Here: the callable really is called, per candidate."""
     og = np.zeros((20, 20), dtype=int)
-    p = amd.RRTStar(og, 10, 5, costfn=lambda vc, pts, v, x: vc[v] + 1.0, pbar=False)
-    with pytest.raises(NotImplementedError):
-        p.plan(np.array([1, 1]), np.array([5, 5]))
+    calls = []
+
+    def cost(vc, pts, v, x):
+        calls.append(int(v))
+        return vc[v] + 1.0  # every edge costs 1: the cost of a vertex is its depth
+
+    p = amd.RRTStar(og, 60, 6, costfn=cost, pbar=False)
+    T, gv = p.plan(np.array([1, 1]), np.array([15, 15]))
+    assert len(calls) > 200 and T.number_of_nodes() == 61
+    depth = {0: 0}
+    for u, v, d in sorted(T.edges(data=True), key=lambda e: e[1]):
+        assert d["cost"] == depth.setdefault(u, 0) + 1.0 or v == gv
+        depth[v] = d["cost"]
 
 
 def test_context_close_takes_its_batches_along():
