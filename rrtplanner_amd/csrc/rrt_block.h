@@ -287,8 +287,12 @@ constexpr int ROLE_ALL = 0, ROLE_COMMIT = 1, ROLE_WORK = 2;
 // by then).
 // INF: the batch may hold Informed queries (alg 2); without it everything the ellipse needs is compiled out.
 
-template <int G, int BSM, bool PIPE, bool INF, int ROLE>
+// CW: waves of THIS workgroup.  16 everywhere, except for a pipelined team's committer launched as a kernel of its own
+// (rrt_block_commit_kernel, RRT_FLAG_SPLIT_COMMIT): 8 waves, so that it is compiled for 256 instead of 128 vector registers.
+template <int G, int BSM, bool PIPE, bool INF, int ROLE, int CW = NWAVE>
 __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PIPE, INF> &L) {
+    static_assert(CW == NWAVE || ROLE == ROLE_COMMIT, "only a committer runs with fewer waves");
+    constexpr int NTG = CW * 64;  // threads of this workgroup
     static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM <= BS && BSM * G <= 64, "team size");
     static_assert(!PIPE || G > 1, "a pipeline needs a team");
     static_assert(PIPE == (ROLE != ROLE_ALL), "roles are the halves of a pipelined team");
@@ -321,7 +325,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     int q = (int)blockIdx.x, g_ = 0;  // query, team member
     if (G > 1) {
         q = (int)blockIdx.x % bv.team_qpad;  // members of one team are 8k blocks apart: dealt to the same XCD (speed only)
-        g_ = (int)blockIdx.x / bv.team_qpad;
+        g_ = (int)blockIdx.x / bv.team_qpad + bv.member0;  // (member0 = 1: the workers' own launch, the committer runs elsewhere)
         if (q >= bv.Q) return;
         if (bv.team_fault && g_ == 1) return;
     }
@@ -444,8 +448,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     //      higher index); cell fill counts from HBM ----
     {
         const uint32_t n0 = nodes_g[0];
-        for (int k = t; k < lds_nodes; k += TPB) nodes_lds[k] = (k < j) ? nodes_g[k] : n0;
-        for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
+        for (int k = t; k < lds_nodes; k += NTG) nodes_lds[k] = (k < j) ? nodes_g[k] : n0;
+        for (int k = t; k < ncells; k += NTG) cellcnt[k] = cellcnt_g[k];
         if (t < SB * 5) statred[t] = 0;
         if (t < NWAVE) L.help_n[t] = 0;
         if (t == 0) L.help_any = 0;
@@ -2029,9 +2033,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                             known |= cb;
                             aknown |= cb & popt;
                         }
-                        // the first NWAVE of them, in sample order: lane k knows its place in the list
+                        // the first CW of them (one per wave of this workgroup), in sample order: lane k knows its place in the list
                         const uint32_t place = (uint32_t)__builtin_popcountll(L0 & ltmask);
-                        const bool listed = ((L0 >> lane) & 1ull) != 0 && place < (uint32_t)NWAVE;
+                        const bool listed = ((L0 >> lane) & 1ull) != 0 && place < (uint32_t)CW;
                         if (listed) par.list[place] = (uint32_t)lane;
                         lastmask = __ballot(listed);
                         cnt = (uint32_t)__builtin_popcountll(lastmask);
@@ -2303,7 +2307,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 
     // cell fill counts back to HBM (a resumed launch reloads them); fold wave 0's statistics
     if (g == 0) {
-        for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
+        for (int k = t; k < ncells; k += NTG) cellcnt_g[k] = cellcnt[k];
     }
     __syncthreads();
 
@@ -2315,8 +2319,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         double pc;
         uint32_t pi;
         const int cnt = j > g ? (j - g + NWG - 1) / NWG : 0;
-        go2goal_phase(og, H, nodes_g, vcost, g, NWG, cnt, xg, reinterpret_cast<uint32_t *>(clist_base), (RRT_LDS uint32_t *)smem, bslots, t, lane,
-                      wave, pc, pi);
+        go2goal_phase<false, NTG>(og, H, nodes_g, vcost, g, NWG, cnt, xg, reinterpret_cast<uint32_t *>(clist_base), (RRT_LDS uint32_t *)smem, bslots, t, lane,
+                                  wave, pc, pi);
         if (G > 1) {
             gu64 *const t_res = (gu64 *)(tb + TEAM_OFF_RES);
             if (g > 0) {
@@ -2432,6 +2436,20 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
     } else {
         rrt_block_body<G, BSM, PIPE, INF, ROLE_ALL>(bv, L);
     }
+}
+
+// RRT_FLAG_SPLIT_COMMIT: the two halves of a pipelined team as two kernels on two streams of the context.  Register allocation is
+// per kernel: the committer, 8 waves, gets 256 vector registers instead of the 128 of a 16-wave workgroup (the one-kernel form
+// spills 33 of them, profiles/r02_resource_usage_role1_committer.txt); the workers are compiled without the committer's code.
+template <int G, int BSM, bool INF>
+__global__ __launch_bounds__(512) void rrt_block_commit_kernel(BatchView bv) {
+    __shared__ BlockLds<G, BSM, true, INF> L;
+    rrt_block_body<G, BSM, true, INF, ROLE_COMMIT, 8>(bv, L);
+}
+template <int G, int BSM, bool INF>
+__global__ __launch_bounds__(TPB) void rrt_block_work_kernel(BatchView bv) {
+    __shared__ BlockLds<G, BSM, true, INF> L;
+    rrt_block_body<G, BSM, true, INF, ROLE_WORK>(bv, L);  // launched with bv.member0 = 1
 }
 
 }  // namespace rrtdev

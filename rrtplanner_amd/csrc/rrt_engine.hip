@@ -55,6 +55,8 @@ struct PinnedDescs {
 struct rrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // RRT_FLAG_SPLIT_COMMIT: the committers' kernel runs here, next to the workers' on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *og = nullptr;      // active grid, device (W,H): og_buf + frame * W * H
     uint8_t *og_buf = nullptr;  // allocation holding 1 uploaded grid or `nframes` generated grids
     size_t og_buf_bytes = 0;
@@ -89,6 +91,7 @@ struct rrt_batch {
     bool pipe = false;          // the last launch ran the pipelined team kernel
     int32_t last_team = 0;      // workers per query of the last launch (1 after a hand-off timed out)
     bool last_inf = false;      // the last launch ran the Informed instantiation
+    bool split = false;         // the last launch ran committers and workers as two kernels (RRT_FLAG_SPLIT_COMMIT)
     int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
     int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
     int32_t team_want = TEAM_MAX;  // the caller's cap on the team size
@@ -221,6 +224,9 @@ extern "C" int rrt_ctx_destroy(rrt_ctx *ctx) {
     if (ctx->single) rrt_batch_destroy(ctx->single);
     (void)rrt_comm_destroy(ctx);
     if (ctx->og_buf) (void)hipFree(ctx->og_buf);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RRT_OK;
@@ -754,6 +760,7 @@ static BatchView make_view(rrt_batch *b) {
     v.Q = b->Q;
     v.team_qpad = b->team_qpad;
     v.team_fault = (b->flags & RRT_FLAG_TEAM_FAULT) ? 1 : 0;
+    v.member0 = 0;
     if (b->d_kids) {
         const size_t qs = (size_t)b->Q * b->node_stride;
         v.kid_first = b->d_kids;
@@ -882,7 +889,29 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         if (team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
         const dim3 tg(team > 1 ? (unsigned)(v.team_qpad * (team + (pipe ? 1 : 0))) : (unsigned)b->Q);
-        hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf), tg, dim3(TPB), blk_lds_bytes, ctx->stream, v);
+        b->split = false;
+        if ((b->flags & RRT_FLAG_SPLIT_COMMIT) && pipe && team == 64 && !inf) {
+            // the committers as a kernel of their own (8 waves, 256 vector registers) on a second stream, the workers on the first:
+            // fork behind the init kernel and the memset, join in front of the read-back
+            if (!ctx->stream2) {
+                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            HIPCHK(ctx, raise_dynamic_lds(ctx->device, reinterpret_cast<const void *>(rrt_block_commit_kernel<64, 1, false>), (int)blk_lds_bytes));
+            HIPCHK(ctx, raise_dynamic_lds(ctx->device, reinterpret_cast<const void *>(rrt_block_work_kernel<64, 1, false>), (int)blk_lds_bytes));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            hipLaunchKernelGGL((rrt_block_commit_kernel<64, 1, false>), dim3((unsigned)v.team_qpad), dim3(512), blk_lds_bytes, ctx->stream2, v);
+            BatchView vw = v;
+            vw.member0 = 1;
+            hipLaunchKernelGGL((rrt_block_work_kernel<64, 1, false>), dim3((unsigned)(v.team_qpad * team)), dim3(TPB), blk_lds_bytes, ctx->stream, vw);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            b->split = true;
+        } else {
+            hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf), tg, dim3(TPB), blk_lds_bytes, ctx->stream, v);
+        }
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;
@@ -979,11 +1008,12 @@ extern "C" int rrt_batch_pipelined(rrt_batch *b, int32_t *pipelined) {
 
 extern "C" int rrt_batch_kernel_name(rrt_batch *b, char *buf, int32_t len) {
     if (!b || !buf || len < 1) return fail(nullptr, RRT_E_ARG, "rrt_batch_kernel_name: bad argument");
-    char tmp[96];
+    char tmp[160];
     if (b->use_block) {
         const int team = b->last_team > 0 ? b->last_team : b->team;
         const int bsm = team <= 4 ? 16 : 64 / team;
-        snprintf(tmp, sizeof tmp, "rrt_expand_block_kernel<%d, %d, %s, %s>", team, bsm, (team > 1 && b->pipe) ? "true" : "false", b->last_inf ? "true" : "false");
+        if (b->split) snprintf(tmp, sizeof tmp, "rrt_block_work_kernel<%d, %d, false> + rrt_block_commit_kernel<%d, %d, false>", team, bsm, team, bsm);
+        else snprintf(tmp, sizeof tmp, "rrt_expand_block_kernel<%d, %d, %s, %s>", team, bsm, (team > 1 && b->pipe) ? "true" : "false", b->last_inf ? "true" : "false");
     } else if (b->dub_block) {
         snprintf(tmp, sizeof tmp, "rrt_dubins_block_kernel");
     } else {

@@ -73,6 +73,7 @@ struct BatchView {
     unsigned char *team;      // [Q][TEAM_BYTES]    block kernel with teams: sync words, state, exchanged records
     int32_t Q, team_qpad;     // queries of the batch; block stride between the members of a team (block = member * team_qpad + query)
     int32_t team_fault;       // testing: member 1 of every team leaves at once (the others' hand-offs time out)
+    int32_t member0;          // added to the member number a team kernel derives from its block index (1: a launch of the workers only)
     // opt-in true rewire (RRT_FLAG_REWIRE; serial kernel only), null otherwise
     int32_t *kid_first, *kid_next, *kid_prev;  // [Q][node_stride] child lists: first child, next / previous sibling (-1 = none)
     uint32_t *frontier;                        // [Q][2 * node_stride] two propagation frontiers
@@ -193,7 +194,8 @@ constexpr int G2G_U = 4;      // nodes a wave tests per round
 
 // The nodes considered are kfirst + m * kstep, m < cnt (all of them: 0, 1, j; a team gives each member a stripe and takes the
 // minimum of the stripes' answers).
-template <bool DUB = false>
+// NT: threads of the calling workgroup (a pipelined team's committer may run as a workgroup of its own with fewer waves).
+template <bool DUB = false, int NT = TPB>
 __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const uint32_t *nodes_g, const double *vcost, int kfirst, int kstep,
                                               int cnt, uint32_t xg, uint32_t *order, RRT_LDS uint32_t *lds16k, BSlot *bslots, int t, int lane,
                                               int wave, double &pc, uint32_t &pi, const uint8_t *heading = nullptr, int hg = 0, DubCfg dc = DubCfg{}) {
@@ -205,7 +207,7 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
     };
     // ---- cost range ----
     double cmin = f64_inf(), cmax = 0.0;
-    for (int m = t; m < cnt; m += TPB) {
+    for (int m = t; m < cnt; m += NT) {
         const double c = cost_of(kfirst + m * kstep);
         cmin = c < cmin ? c : cmin;
         cmax = c > cmax ? c : cmax;
@@ -227,7 +229,7 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
         }
         __syncthreads();
         double a = f64_inf(), b = 0.0;
-        for (int w = 0; w < NWAVE; ++w) {
+        for (int w = 0; w < NT / 64; ++w) {
             const double x = bslots[w].pc, y = bslots[w].uc;
             a = x < a ? x : a;
             b = y > b ? y : b;
@@ -243,15 +245,22 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
         return b > (uint32_t)(G2G_NB - 1) ? (uint32_t)(G2G_NB - 1) : b;
     };
     // ---- histogram, exclusive scan, scatter ----
-    for (int b = t; b < 2 * G2G_NB; b += TPB) lds16k[b] = 0;
+    for (int b = t; b < 2 * G2G_NB; b += NT) lds16k[b] = 0;
     __syncthreads();
-    for (int m = t; m < cnt; m += TPB)
+    for (int m = t; m < cnt; m += NT)
         __hip_atomic_fetch_add(&cursor[bucket_of(cost_of(kfirst + m * kstep))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
     {
-        // thread t owns buckets 2t, 2t+1 (G2G_NB == 2 * TPB)
-        const uint32_t c0 = cursor[2 * t], c1 = cursor[2 * t + 1];
-        uint32_t incl = c0 + c1;
+        // thread t owns the PB consecutive buckets PB t .. PB t + PB - 1 (G2G_NB == PB * NT)
+        constexpr int PB = G2G_NB / NT;
+        static_assert(PB * NT == G2G_NB, "buckets per thread");
+        uint32_t cb[PB], own = 0;
+#pragma unroll
+        for (int e = 0; e < PB; ++e) {
+            cb[e] = cursor[PB * t + e];
+            own += cb[e];
+        }
+        uint32_t incl = own;
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
@@ -262,14 +271,16 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
         __syncthreads();
         uint32_t base = 0;
         for (int w = 0; w < wave; ++w) base += bslots[w].pi;
-        const uint32_t ex = base + incl - (c0 + c1);
-        cursor[2 * t] = ex;
-        bend[2 * t] = ex + c0;
-        cursor[2 * t + 1] = ex + c0;
-        bend[2 * t + 1] = ex + c0 + c1;
+        uint32_t ex = base + incl - own;
+#pragma unroll
+        for (int e = 0; e < PB; ++e) {
+            cursor[PB * t + e] = ex;
+            ex += cb[e];
+            bend[PB * t + e] = ex;
+        }
         __syncthreads();
     }
-    for (int m = t; m < cnt; m += TPB) {
+    for (int m = t; m < cnt; m += NT) {
         const int k = kfirst + m * kstep;
         const uint32_t pos = __hip_atomic_fetch_add(&cursor[bucket_of(cost_of(k))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         order[pos] = (uint32_t)k;
@@ -280,12 +291,12 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
     pi = NONE;
     uint32_t limit = (uint32_t)cnt;
     int round = 0;
-    for (uint32_t pos0 = 0; pos0 < limit; pos0 += NWAVE * G2G_U) {
+    for (uint32_t pos0 = 0; pos0 < limit; pos0 += (NT / 64) * G2G_U) {
         double bc = f64_inf();
         uint32_t bi = NONE;
 #pragma unroll
         for (int u = 0; u < G2G_U; ++u) {
-            const uint32_t p = pos0 + (uint32_t)(u * NWAVE + wave);
+            const uint32_t p = pos0 + (uint32_t)(u * (NT / 64) + wave);
             if (p < limit) {
                 const uint32_t k = order[p];
                 int cc = 0;
@@ -313,7 +324,7 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
         __syncthreads();
         double rc = f64_inf();
         uint32_t ri = NONE;
-        if (lane < NWAVE) {
+        if (lane < NT / 64) {
             rc = sl[lane].pc;
             ri = sl[lane].pi;
         }

@@ -48,17 +48,21 @@ for f in ("q_default","q_c4_team1","q_c3","q_c2_team1"):
 PY
     ;;
 prof)
-    for c in 2 3 4; do
+    for c in 2 3 4 5; do
         rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline --no-batched > $O/prof_c$c.json 2> $O/prof_c$c.err
         echo "prof c$c rc=$?"
+        f=$(ls -t $O/prof_c$c/*/*kernel_stats.csv 2>/dev/null | head -n 1); [ -n "$f" ] && cp $f $O/config${c}_kernel_stats.csv
     done ;;
 pmc)
-    for spec in "2 1" "3 1" "4 64" "2 8" "2 256"; do
+    SPECS=("2 1" "3 1" "4 64" "2 8" "2 256" "5 256")
+    for spec in "${SPECS[@]}"; do
         set -- $spec; c=$1; q=$2
-        for ctr in FETCH_SIZE WRITE_SIZE; do
-            rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_c${c}_q${q}_$ctr -- python3 $R/bench.py --config $c --queries $q --steps 2 --warmup 1 --no-cpu-baseline --no-batched > $O/pmc_c${c}_q${q}_$ctr.json 2> $O/pmc_c${c}_q${q}_$ctr.err
-            echo "pmc c$c q$q $ctr rc=$?"
+        for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
+            name=${ctr%% *}
+            rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_c${c}_q${q}_$name -- python3 $R/bench.py --config $c --queries $q --steps 2 --warmup 1 --no-cpu-baseline --no-batched > $O/pmc_c${c}_q${q}_$name.json 2> $O/pmc_c${c}_q${q}_$name.err
+            echo "pmc c$c q$q $name rc=$?"
         done
-    done ;;
+    done
+    (cd $R && python3 tools/pmc_to_json.py $O "${SPECS[@]}" && cp profiles/r03_traffic.json profiles/r03_sq_counters.json $O/) ;;
 esac
 done

@@ -18,11 +18,12 @@ ap.add_argument("--queries", type=int, default=1)
 ap.add_argument("--grid", type=int, default=1024)
 ap.add_argument("--team", type=int, default=None, help="CUs per query: 1, 2, 4 (default: as many as fit)")
 ap.add_argument("--serial", action="store_true")
+ap.add_argument("--split", action="store_true", help="RRT_FLAG_SPLIT_COMMIT: committer and workers as two kernels")
 a = ap.parse_args()
 og = perlin_occupancygrid(a.grid, a.grid, seed=1)
 free = np.argwhere(og == 0)
 ctx = _ffi.Context(0); ctx.set_grid(hostprep.og_nonzero(og))
-b = _ffi.Batch(ctx, a.queries, a.n, serial=a.serial, team=a.team)
+b = _ffi.Batch(ctx, a.queries, a.n, serial=a.serial, team=a.team, split=a.split)
 sg = np.random.default_rng(7); keep = []
 for q in range(a.queries):
     xs, xg = random_connected_pair(og, sg)
@@ -38,7 +39,7 @@ cyc = b.debug_cycles(0)
 names = (["A scan+wave-reduce", "barrier 1", "B nearest+LoS+dup", "C choose parent", "D insert", "go2goal"] if a.serial else
          ["A scan + reductions", "barrier (scan skew)", "B owner phase (wave 0)", "barrier (owner tail)", "C wait members + commit", "go2goal"])
 tot = sum(cyc) or 1
-print(f"kernel {ms:.2f} ms, n={a.n}, nodes={r.c.j}, iters/s={a.n/ms*1e3:.0f}, status={r.c.status}")
+print(f"kernel {ms:.2f} ms ({b.kernel_name()}), n={a.n}, nodes={r.c.j}, iters/s={a.n/ms*1e3:.0f}, status={r.c.status}")
 w = cyc[6:]; cyc = cyc[:6]
 print("per-wave owner-phase cyc/iter:", [round(x / a.n) for x in w[:16]])
 print("per-wave near-set part cyc/iter:", [round(x / a.n) for x in w[16:]])
