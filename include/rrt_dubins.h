@@ -46,7 +46,15 @@ typedef struct {
 } dub_path_t;
 
 /* ---- elementary functions with a fixed operation order ------------------------------------------------------------ */
-RRT_DUB_FN double dub_mod2pi(double a) { return a - DUB_TWOPI * floor(a / DUB_TWOPI); }
+/* a mod 2 pi in [0, 2 pi).  The quotient comes from a multiplication by 1 / (2 pi) (a word evaluation makes 21 of these: as
+ * divisions they were a seventh of its instructions); the product may land on the other side of an integer by an ulp, which the
+ * two selects behind it put right. */
+#define DUB_INV_TWOPI 0.15915494309189535
+RRT_DUB_FN double dub_mod2pi(double a) {
+    double r = a - DUB_TWOPI * floor(a * DUB_INV_TWOPI);
+    r = r < 0.0 ? r + DUB_TWOPI : r;
+    return r >= DUB_TWOPI ? r - DUB_TWOPI : r;
+}
 
 /* sin and cos of a (|a| up to a few hundred): quadrant by Cody-Waite reduction with a two-part pi/2, then the Taylor
  * polynomials on [-pi/4, pi/4] (truncation below 1e-17). */
@@ -74,29 +82,28 @@ RRT_DUB_FN void dub_sincos(double a, double *s, double *c) {
     }
 }
 
-/* atan of z in [0, 1]: one argument reduction at tan(pi/8), then the alternating series in w^2 (|w| <= 0.4143, 21 terms:
- * truncation below 1e-17) */
-RRT_DUB_FN double dub_atan01(double z) {
-    double base = 0.0, w = z;
-    if (z > 0.41421356237309503) {
-        w = (z - 1.0) / (z + 1.0);
+/* atan(num / den) for 0 <= num <= den, den > 0, with ONE division: the quotient's sixteenth of pi is found by comparing num with
+ * den * tan((2k - 1) pi / 32), then atan(num / den) = k pi / 16 + atan(w) with w = (num - t den) / (den + t num), t = tan(k pi / 16),
+ * |w| <= tan(pi / 32) = 0.0985, and the alternating series in w^2 needs 8 terms (truncation below 5e-18 relative).  (Round 2:
+ * quotient, one reduction at tan(pi / 8), 21 terms -- two divisions and 42 dependent operations per arctangent.) */
+RRT_DUB_FN double dub_atan_ratio(double num, double den) {
+    double t = 0.0, base = 0.0;
+    if (num > den * 0.8206787908286602) { /* tan(7 pi / 32) */
+        t = 1.0;
         base = 0.7853981633974483;
+    } else if (num > den * 0.5345111359507916) { /* tan(5 pi / 32) */
+        t = 0.6681786379192989; /* tan(3 pi / 16) */
+        base = 0.5890486225480862;
+    } else if (num > den * 0.3033466836073424) { /* tan(3 pi / 32) */
+        t = 0.41421356237309503; /* tan(pi / 8) */
+        base = 0.39269908169872414;
+    } else if (num > den * 0.09849140335716425) { /* tan(pi / 32) */
+        t = 0.198912367379658; /* tan(pi / 16) */
+        base = 0.19634954084936207;
     }
+    const double w = (num - t * den) / (den + t * num);
     const double u = w * w;
-    double acc = 1.0 / 41.0;
-    acc = 1.0 / 39.0 - u * acc;
-    acc = 1.0 / 37.0 - u * acc;
-    acc = 1.0 / 35.0 - u * acc;
-    acc = 1.0 / 33.0 - u * acc;
-    acc = 1.0 / 31.0 - u * acc;
-    acc = 1.0 / 29.0 - u * acc;
-    acc = 1.0 / 27.0 - u * acc;
-    acc = 1.0 / 25.0 - u * acc;
-    acc = 1.0 / 23.0 - u * acc;
-    acc = 1.0 / 21.0 - u * acc;
-    acc = 1.0 / 19.0 - u * acc;
-    acc = 1.0 / 17.0 - u * acc;
-    acc = 1.0 / 15.0 - u * acc;
+    double acc = 1.0 / 15.0;
     acc = 1.0 / 13.0 - u * acc;
     acc = 1.0 / 11.0 - u * acc;
     acc = 1.0 / 9.0 - u * acc;
@@ -111,10 +118,9 @@ RRT_DUB_FN double dub_atan01(double z) {
 RRT_DUB_FN double dub_atan2(double y, double x) {
     const double ax = x < 0.0 ? -x : x, ay = y < 0.0 ? -y : y;
     if (ax == 0.0 && ay == 0.0) return 0.0;
-    /* ONE quotient and ONE series whichever octant (the same operations on the same operands as two calls behind a branch,
-     * but a wavefront whose lanes disagree about the octant no longer runs the 21-term series twice) */
+    /* ONE series whichever octant: the smaller magnitude over the larger */
     const int steep = !(ay <= ax);
-    const double t = dub_atan01((steep ? ax : ay) / (steep ? ay : ax));
+    const double t = dub_atan_ratio(steep ? ax : ay, steep ? ay : ax);
     double a = steep ? 1.5707963267948966 - t : t;
     if (x < 0.0) a = DUB_PI - a;
     return y < 0.0 ? -a : a;
@@ -241,7 +247,7 @@ RRT_DUB_FN void dub_advance(double x, double y, double th, int32_t kind, double 
 
 /* the sweep of one path, prepared once per path: the poses at the two junctions (normalised, relative to the start) */
 typedef struct {
-    double x0, y0, th0, rho;
+    double x0, y0, th0, rho, inv_rho;
     double t, p, q;
     double x1, y1, th1; /* pose after the first segment */
     double x2, y2, th2; /* pose after the second segment */
@@ -300,6 +306,7 @@ RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const d
     s.y0 = y0;
     s.th0 = th0;
     s.rho = rho;
+    s.inv_rho = 1.0 / rho;
     s.t = path->t;
     s.p = path->p;
     s.q = path->q;
@@ -317,7 +324,7 @@ RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const d
 
 /* grid cell of sample k (arc length k * DUB_DS from the start) */
 RRT_DUB_FN void dub_sweep_cell(const dub_sweep_t *s, int32_t k, int32_t *cx, int32_t *cy) {
-    const double tau = ((double)k * DUB_DS) / s->rho; /* normalised arc length */
+    const double tau = ((double)k * DUB_DS) * s->inv_rho; /* normalised arc length (one division per sweep, not per sample) */
     /* the segment the sample lies on is selected first, then ONE advance (same operands as one call per branch) */
     double bx = s->x2, by = s->y2, bth = s->th2, bs = s->sn2, bc = s->cs2, dt = tau - (s->t + s->p), x, y;
     int32_t kind = s->k2;

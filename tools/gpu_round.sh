@@ -30,7 +30,22 @@ bench)
     python3 $R/bench.py --queries 8 --no-cpu-baseline --no-batched > $O/bench_config2_q8.json 2>/dev/null
     python3 $R/bench.py --queries 256 --no-cpu-baseline --no-batched > $O/bench_config2_q256.json 2>/dev/null
     for t in 1 2 4 8 16 32; do python3 $R/bench.py --team $t --no-cpu-baseline --no-batched > $O/bench_config2_team$t.json 2>/dev/null; done
-    for t in 1 2 4 8; do python3 $R/bench.py --config 4 --team $t --no-cpu-baseline > $O/bench_config4_team$t.json 2>/dev/null; done ;;
+    for t in 1 2 4 8; do python3 $R/bench.py --config 4 --team $t --no-cpu-baseline > $O/bench_config4_team$t.json 2>/dev/null; done
+    python3 $R/bench.py --config 5 --steps 3 --warmup 1 > $O/bench_config5.json 2> $O/bench_config5.err; echo "bench c5 rc=$?"
+    python3 $R/bench.py --config 5 --serial --queries 16 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_config5_serial_q16.json 2>/dev/null
+    python3 $R/bench.py --config 5 --queries 16 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_config5_q16.json 2>/dev/null
+    python3 - <<PY
+import json, glob, os
+for f in sorted(glob.glob("$O/bench_*.json")):
+    try:
+        d = json.load(open(f)); r = d["roofline"]; m = r.get("measured") or {}
+        print("%-32s ms/step %8.3f kernel %8.3f gap %6.3f value %.4g cus %s frac %s measured_frac %s" % (os.path.basename(f), d["ms_per_step"], r["kernel_ms"], d.get("host_gap_ms", 0), d["value"], d["config"]["cus_per_query"], r["frac"], m.get("hbm_frac")))
+        b = d.get("batched")
+        if b: print("%-32s ms/step %8.3f kernel %8.3f value %.4g cus %s" % ("  batched leg", b["ms_per_step"], b["roofline"]["kernel_ms"], b["value"], b["cus_per_query"]))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
+    ;;
 quick)
     python3 $R/bench.py --no-cpu-baseline > $O/q_default.json 2>$O/q_default.err; echo "default rc=$?"
     python3 $R/bench.py --config 4 --team 1 --no-cpu-baseline > $O/q_c4_team1.json 2>/dev/null
