@@ -32,7 +32,8 @@ extern "C" {
 #define RRT_E_GOAL_UNREACHABLE (-2) /* rrt.py:317-318 would index og[INT64_MIN,..]: no line of sight, j < n */
 #define RRT_E_HIP (-3)
 #define RRT_E_NOGRID (-4)
-#define RRT_E_UNSUPPORTED (-5)     /* grid larger than 2048 x 2048 (packed-key fast path), n > 262143 */
+#define RRT_E_UNSUPPORTED (-5)     /* rrt_batch_create / rrt_plan: grid larger than 2048 x 2048 or n > 262143 (the expansion kernels' packed keys; such a
+                                      planner runs host-driven over rrt_tree_query instead, slower, same results); rrt_set_grid: more than 32767 cells per axis */
 #define RRT_E_COMM (-6)            /* multi-GPU gather: librccl missing, no communicator, RCCL error, unequal slabs */
 
 #define RRT_ALG_STANDARD 0 /* RRTStandard.plan     rrt.py:386 */
@@ -121,7 +122,9 @@ typedef struct rrt_result {
 int rrt_ctx_create(int32_t device_id, rrt_ctx **out);
 int rrt_ctx_destroy(rrt_ctx *ctx); /* destroy the batches created on a context before the context itself */
 const char *rrt_last_error_string(rrt_ctx *ctx); /* ctx may be NULL */
-/* RRT.__init__ / set_og (rrt.py:64-65, :261-272): og_nonzero is (W,H) C-order, 1 = obstacle. */
+/* RRT.__init__ / set_og (rrt.py:64-65, :261-272): og_nonzero is (W,H) C-order, 1 = obstacle.  Up to 32767 cells per axis; the
+ * expansion kernels (rrt_batch_*, rrt_plan*) take grids up to 2048 x 2048, larger ones serve rrt_tree_query and
+ * rrt_prim_collisionfree only. */
 int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, int32_t H);
 
 /* Device-resident noise grids (counterpart of oggen.perlin_occupancygrid, oggen.py:7-45: fractal gradient noise, min-max

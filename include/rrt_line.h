@@ -78,4 +78,19 @@ RRT_LINE_FN void rrt_line_cell(const rrt_line_t *l, int32_t k, int32_t *x, int32
     }
 }
 
+/* The same cell without the 2^24 limit (grids up to 32767 x 32767: the slow general path of the host-driven planners): the
+ * quotient by 64-bit integer division. */
+RRT_LINE_FN void rrt_line_cell_wide(const rrt_line_t *l, int32_t k, int32_t *x, int32_t *y) {
+    const int64_t den = 2 * (int64_t)l->major;
+    const int64_t num = 2 * (int64_t)l->minor * (int64_t)k + (int64_t)l->major;
+    const int32_t m = den == 0 ? 0 : (int32_t)(num / den);
+    if (l->xmajor) {
+        *x = l->x0 + l->sx * k;
+        *y = l->y0 + l->sy * m;
+    } else {
+        *x = l->x0 + l->sx * m;
+        *y = l->y0 + l->sy * k;
+    }
+}
+
 #endif /* RRT_LINE_H */

@@ -99,10 +99,30 @@ __device__ __forceinline__ double sqrt_u32(uint32_t d2) { return sqrt((double)d2
 // the first blocked cell.  `cells` = grid cells the reference's serial walk reads
 // before returning (first blocked cell + 1, or L+1).  Result uniform.  Long segments keep four
 // 64-cell groups of loads in flight.
+// WIDE: grids beyond 2048 x 2048 (host-driven planners only): the cell of the walk by 64-bit division (rrt_line_cell_wide).
+template <bool WIDE = false>
 __device__ __forceinline__ bool los_wave(const uint8_t *__restrict__ og, int H, uint32_t a, uint32_t b, int lane,
                                          int &cells) {
     rrt_line_t l = rrt_line_setup(ux(a), uy(a), ux(b), uy(b));
     const int L = l.major;
+    if (WIDE) {
+        for (int k0 = 0; k0 <= L; k0 += 64) {
+            bool occ = false;
+            const int k = k0 + lane;
+            if (k <= L) {
+                int x, y;
+                rrt_line_cell_wide(&l, k, &x, &y);
+                occ = og[(uint32_t)x * (uint32_t)H + (uint32_t)y] != 0;
+            }
+            const unsigned long long m = __ballot(occ);
+            if (m) {
+                cells = k0 + (int)__builtin_ctzll(m) + 1;
+                return false;
+            }
+        }
+        cells = L + 1;
+        return true;
+    }
     if (L < 64) {
         bool occ = false;
         if (lane <= L) {

@@ -25,6 +25,9 @@ using namespace rrtdev;
 
 static thread_local std::string g_last_error;
 
+constexpr int RRT_GRID_FAST = 2048;  // the expansion kernels: coordinates below 2^11, squared distances below 2^24 (packed scan keys, sqrt_u24)
+constexpr int RRT_GRID_MAX = 32767;  // the host-driven path (rrt_tree_query, rrt_prim_collisionfree): 16-bit packed coordinates whose differences fit int16
+
 // Host copy of a batch's query descriptors in page-locked memory: the per-step copies to and from the device (rrt_batch_rearm,
 // rrt_batch_sync) are then plain DMA transfers in stream order, with no staging copy and no hidden synchronisation.
 struct PinnedDescs {
@@ -234,8 +237,8 @@ extern "C" int rrt_ctx_destroy(rrt_ctx *ctx) {
 
 extern "C" int rrt_set_grid(rrt_ctx *ctx, const uint8_t *og_nonzero, int32_t W, int32_t H) {
     if (!ctx || !og_nonzero || W < 1 || H < 1) return fail(ctx, RRT_E_ARG, "rrt_set_grid: bad argument");
-    if (W > 2048 || H > 2048)
-        return fail(ctx, RRT_E_UNSUPPORTED, "rrt_set_grid: %dx%d exceeds the 2048x2048 packed-key path", W, H);
+    if (W > RRT_GRID_MAX || H > RRT_GRID_MAX)
+        return fail(ctx, RRT_E_UNSUPPORTED, "rrt_set_grid: %dx%d exceeds %d cells per axis (16-bit packed coordinates)", W, H, RRT_GRID_MAX);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->og_buf && ctx->og_buf_bytes != (size_t)W * H) {
@@ -507,6 +510,9 @@ static TeamShape pick_team(int Q, int want, bool allow_pipe, int cus) {
 extern "C" int rrt_batch_create(rrt_ctx *ctx, int32_t Q, int32_t n_cap, uint32_t flags, rrt_batch **out) {
     if (!ctx || !out || Q < 1 || n_cap < 1) return fail(ctx, RRT_E_ARG, "rrt_batch_create: bad argument");
     if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_batch_create: call rrt_set_grid first");
+    if (ctx->W > RRT_GRID_FAST || ctx->H > RRT_GRID_FAST)
+        return fail(ctx, RRT_E_UNSUPPORTED, "rrt_batch_create: the expansion kernels take grids up to %dx%d (24-bit squared distances); a %dx%d grid runs "
+                    "through the host-driven path (rrt_tree_query)", RRT_GRID_FAST, RRT_GRID_FAST, ctx->W, ctx->H);
     if ((long long)n_cap + 1 > 64LL * CHUNK)
         return fail(ctx, RRT_E_UNSUPPORTED, "rrt_batch_create: n=%d exceeds %d nodes", n_cap, 64 * CHUNK - 1);
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1397,7 +1403,7 @@ extern "C" int rrt_tree_destroy(rrt_tree *t) {
 
 extern "C" int rrt_tree_create(rrt_ctx *ctx, int32_t capacity, rrt_tree **out) {
     if (!ctx || !out || capacity < 1) return fail(ctx, RRT_E_ARG, "rrt_tree_create: bad argument");
-    if ((long long)capacity > 64LL * CHUNK) return fail(ctx, RRT_E_UNSUPPORTED, "rrt_tree_create: capacity %d exceeds %d vertices", capacity, 64 * CHUNK);
+    if (capacity > (1 << 24)) return fail(ctx, RRT_E_UNSUPPORTED, "rrt_tree_create: capacity %d exceeds %d vertices", capacity, 1 << 24);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     rrt_tree *t = new rrt_tree();
     t->ctx = ctx;
@@ -1429,7 +1435,7 @@ extern "C" int rrt_tree_append(rrt_tree *t, int32_t x, int32_t y, int32_t *index
     if (!t) return fail(nullptr, RRT_E_ARG, "rrt_tree_append: NULL");
     rrt_ctx *ctx = t->ctx;
     if (t->j >= t->cap) return fail(ctx, RRT_E_ARG, "rrt_tree_append: the tree holds its %d vertices", t->cap);
-    if (x < 0 || x >= 2048 || y < 0 || y >= 2048) return fail(ctx, RRT_E_ARG, "rrt_tree_append: (%d, %d) outside [0, 2048)^2", x, y);
+    if (x < 0 || x >= RRT_GRID_MAX || y < 0 || y >= RRT_GRID_MAX) return fail(ctx, RRT_E_ARG, "rrt_tree_append: (%d, %d) outside [0, %d)^2", x, y, RRT_GRID_MAX);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     t->h_nodes[t->j] = ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16);
     HIPCHK(ctx, hipMemcpyAsync(t->d_nodes + t->j, t->h_nodes + t->j, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1448,10 +1454,13 @@ extern "C" int rrt_tree_query(rrt_tree *t, int32_t x, int32_t y, int64_t r2, int
     if (x < 0 || x >= ctx->W || y < 0 || y >= ctx->H) return fail(ctx, RRT_E_ARG, "rrt_tree_query: (%d, %d) outside the %dx%d grid", x, y, ctx->W, ctx->H);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int dcap = cap < t->cap ? cap : t->cap;
-    const int64_t capd2 = 1 << 24;
+    const int64_t capd2 = 0x7fffffff;  // any squared distance of 15-bit coordinates is below 2^31
     const uint32_t r2c = (uint32_t)(r2 < 0 ? 0 : (r2 > capd2 ? capd2 : r2));
     const uint32_t xq = ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16);
-    hipLaunchKernelGGL(tree_query_kernel, dim3(1), dim3(TPB), 0, ctx->stream, ctx->og, ctx->H, t->d_nodes, t->j, xq, r2c, dcap, t->d_out, t->d_los);
+    if (ctx->W > RRT_GRID_FAST || ctx->H > RRT_GRID_FAST)
+        hipLaunchKernelGGL(tree_query_kernel<true>, dim3(1), dim3(TPB), 0, ctx->stream, ctx->og, ctx->H, t->d_nodes, t->j, xq, r2c, dcap, t->d_out, t->d_los);
+    else
+        hipLaunchKernelGGL(tree_query_kernel<false>, dim3(1), dim3(TPB), 0, ctx->stream, ctx->og, ctx->H, t->d_nodes, t->j, xq, r2c, dcap, t->d_out, t->d_los);
     HIPCHK(ctx, hipGetLastError());
     // the usual answer (a few dozen rows) comes back in one copy of each array; a longer list in a second pair
     const int first = dcap < 256 ? dcap : 256;
@@ -1494,8 +1503,12 @@ extern "C" int rrt_prim_collisionfree(rrt_ctx *ctx, const int32_t *ab, int32_t m
     HIPCHK(ctx, tmp.alloc(&d_free, (size_t)m));
     HIPCHK(ctx, hipMemcpyAsync(d_ab, ab, (size_t)m * 4 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     const int waves_per_block = 4;
-    hipLaunchKernelGGL(prim_los_kernel, dim3((unsigned)((m + waves_per_block - 1) / waves_per_block)), dim3(64 * waves_per_block), 0,
-                       ctx->stream, ctx->og, ctx->H, d_ab, m, d_free, d_cells);
+    if (ctx->W > RRT_GRID_FAST || ctx->H > RRT_GRID_FAST)
+        hipLaunchKernelGGL(prim_los_kernel<true>, dim3((unsigned)((m + waves_per_block - 1) / waves_per_block)), dim3(64 * waves_per_block), 0,
+                           ctx->stream, ctx->og, ctx->H, d_ab, m, d_free, d_cells);
+    else
+        hipLaunchKernelGGL(prim_los_kernel<false>, dim3((unsigned)((m + waves_per_block - 1) / waves_per_block)), dim3(64 * waves_per_block), 0,
+                           ctx->stream, ctx->og, ctx->H, d_ab, m, d_free, d_cells);
     HIPCHK(ctx, hipMemcpyAsync(out_free, d_free, (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
     if (out_cells) HIPCHK(ctx, hipMemcpyAsync(out_cells, d_cells, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -7,14 +7,15 @@
 
 namespace rrtdev {
 
-// RRT.collisionfree (rrt.py:183-229): one wavefront per segment.
+// RRT.collisionfree (rrt.py:183-229): one wavefront per segment.  WIDE: grids beyond 2048 x 2048 (see los_wave).
+template <bool WIDE>
 __global__ void prim_los_kernel(const uint8_t *og, int H, const int32_t *ab, int m, uint8_t *out_free, int32_t *out_cells) {
     const int lane = (int)(threadIdx.x & 63);
     const int seg = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (seg >= m) return;  // whole wave
     const uint32_t a = pack_xy(ab[4 * seg], ab[4 * seg + 1]), b = pack_xy(ab[4 * seg + 2], ab[4 * seg + 3]);
     int cells = 0;
-    const bool ok = los_wave(og, H, a, b, lane, cells);
+    const bool ok = los_wave<WIDE>(og, H, a, b, lane, cells);
     if (lane == 0) {
         out_free[seg] = (uint8_t)ok;
         out_cells[seg] = cells;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(TPB) void prim_nn_kernel(const uint32_t *nodes, int
 //   los[1 + k]  collisionfree(within[k] -> x)      (rrt.py:519, :537: the same direction in both loops)
 // One workgroup; thread t owns the contiguous rows [t * per, (t + 1) * per), so that its hits are ascending and the
 // hits of the threads concatenate in ascending order (exclusive prefix sum of the per-thread counts).
+template <bool WIDE>
 __global__ __launch_bounds__(TPB) void tree_query_kernel(const uint8_t *og, int H, const uint32_t *nodes, int j, uint32_t xq, uint32_t r2, int cap,
                                                          int32_t *out, uint8_t *los) {
     __shared__ uint32_t wtot[NWAVE];
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(TPB) void tree_query_kernel(const uint8_t *og, int 
     for (int s = wave; s < nseg; s += NWAVE) {
         const uint32_t a = nodes[s == 0 ? (int)ni : out[2 + s - 1]];
         int cells = 0;
-        const bool ok = los_wave(og, H, a, xq, lane, cells);
+        const bool ok = los_wave<WIDE>(og, H, a, xq, lane, cells);
         if (lane == 0) los[s] = (uint8_t)ok;
     }
 }

@@ -10,6 +10,11 @@ grid comes from the device, once per iteration (``rrt_tree_query``, include/rrt_
 lines of sight of :424/:506, :519 and :537 (one direction, vertex -> sample, serves both loops).  There is no CPU fallback:
 the provider is an ``_ffi.DeviceTree``; the tests substitute a numpy stand-in to check the loop itself on a machine without a GPU.
 
+The same loop is the GENERAL path for problems the expansion kernels do not take (grids beyond 2048 x 2048, n beyond 262 143:
+packed 24-bit keys) with the reference's DEFAULT cost: there the per-candidate Python calls are replaced by their numpy form
+(`vcosts[v] + sqrt(d2)`, rrt.py:72-78), and the rewire block, which cannot fire with that cost (rrt.py:532-536), is skipped.
+Slower than the kernels by orders of magnitude, same results: the class has no size at which it refuses.
+
 Tie policy as everywhere: lowest index among equal distance / equal cost.
 """
 import math
@@ -56,6 +61,7 @@ def plan_with_costfn(planner, alg, xstart, xgoal, prov, pbar=None):
     callable.  Returns (vgoal, points, parents, vcosts) as handed to build_graph (rrt.py:334)."""
     n = int(planner.n)
     cost = planner.cost
+    default_cost = not getattr(planner, "_custom_cost", True)  # the closure of rrt.py:72-78: evaluated with numpy, rewire skipped
     og = np.asarray(planner.og)
     W = og.shape[0]
     star, informed = alg >= 1, alg == 2
@@ -88,7 +94,18 @@ def plan_with_costfn(planner, alg, xstart, xgoal, prov, pbar=None):
             sampled.add((x0, x1))
             vbest = vnearest
             cbest = cost(vcosts, points, vbest, xnew)
-            if star:
+            if star and default_cost:
+                # rrt.py:513-521 with the default cost, all candidates at once: the walk ends at the (cost, index)-smallest visible
+                # entry strictly below the cost through the nearest vertex (unfilled rows cost inf and never qualify)
+                vl = np.asarray(vlive, dtype=np.int64)
+                if vl.size:
+                    d = points[vl] - xnew
+                    cn = vcosts[vl] + np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64))
+                    ok = np.flatnonzero(np.asarray(los_live, dtype=bool) & (cn < cbest))
+                    if ok.size:
+                        k = ok[np.argmin(cn[ok])]  # first minimum: lowest index among equal costs
+                        vbest, cbest = int(vl[k]), cn[k]
+            elif star:
                 # within() runs over all n rows (rrt.py:176-181): an unfilled row holds INT64_MIN, its squared distance wraps to
                 # |xnew|^2, so every unfilled row (row j included) is "within" when the sample lies that close to the origin
                 vnear = [int(v) for v in vlive]
@@ -114,8 +131,8 @@ def plan_with_costfn(planner, alg, xstart, xgoal, prov, pbar=None):
             vcosts[vnew] = cbest
             parents[vnew] = vbest
             children[vbest].append(vnew)
-            if star:
-                for vn in vnear:  # rewire, rrt.py:531-546 / :731-742
+            if star and not default_cost:
+                for vn in vnear:  # rewire, rrt.py:531-546 / :731-742 (never true with the default cost: rrt.py:532-536)
                     cn = vcosts[vn]
                     cmaybe = cost(vcosts, points, vn, xnew)
                     if cmaybe < cn:
@@ -140,8 +157,13 @@ def plan_with_costfn(planner, alg, xstart, xgoal, prov, pbar=None):
         i += 1
     # go2goal, rrt.py:311-332: the callable prices every row, then the rows are tried in stable (cost, index) order
     costs = np.empty(vcosts.shape)
-    for k in range(points.shape[0]):
-        costs[k] = cost(vcosts, points, k, xgoal)
+    if default_cost:
+        with np.errstate(over="ignore"):
+            d = points - np.asarray(xgoal)
+            costs[:] = vcosts + np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64))  # (unfilled rows: inf + anything)
+    else:
+        for k in range(points.shape[0]):
+            costs[k] = cost(vcosts, points, k, xgoal)
     order = np.argsort(costs, kind="stable")
     xg0, xg1 = int(xgoal[0]), int(xgoal[1])
     vgoal = None

@@ -7,7 +7,7 @@ import math
 import numpy as np
 
 INT64_MIN = np.iinfo(np.int64).min
-_D2_CAP = 1 << 24  # larger than any squared distance on a 2048 x 2048 grid
+_D2_CAP = (1 << 31) - 1  # larger than any squared distance of 15-bit coordinates (the expansion kernels clamp to 2^24 themselves: grids up to 2048 x 2048)
 
 
 def og_nonzero(og) -> np.ndarray:

@@ -411,10 +411,19 @@ class RRT(object):
                 prov.close()
         return self.build_graph(vgoal, points, parents, vcosts), vgoal
 
+    FAST_GRID_MAX = 2048    # the expansion kernels: packed 24-bit squared distances
+    FAST_N_MAX = 262143     # ... and node index + chunk tag in one 32-bit key
+
+    def _beyond_the_kernels(self) -> bool:
+        W, H = np.asarray(self.og).shape
+        return W > self.FAST_GRID_MAX or H > self.FAST_GRID_MAX or int(self.n) > self.FAST_N_MAX
+
     def _plan(self, alg, xstart, xgoal, **kw):
-        if self._custom_cost:
+        if self._custom_cost or self._beyond_the_kernels():
+            # the host-driven loop over the device primitives (hostloop.py): a custom cost function, or a problem larger than the
+            # expansion kernels take (there with the default cost in numpy form) -- slower, same results, never a refusal
             if kw.get("rewire"):
-                raise ValueError('rewire="correct" is defined for the default cost only; a custom costfn runs the reference\'s own rewire block')
+                raise ValueError('rewire="correct" runs on the expansion kernels only (default cost, grids up to 2048 x 2048, n up to 262143)')
             return None, self._plan_costfn(alg, xstart, xgoal)
         bar = tqdm(total=self.n) if self.pbar else None
         try:

@@ -292,3 +292,32 @@ def test_unknown_networkx_layout_falls_back_to_public_calls(monkeypatch):
     assert p.route2gv(slow, 3) == p.route2gv(fast, 3) == [0, 1, 3]
     g = p.build_graph(3, points, {0: None, 1: 0, 2: 0, 3: 1}, vcosts)  # the public method, also on the slow path now
     assert list(g.edges(data=True)) == list(fast.edges(data=True))
+
+
+@pytest.mark.parametrize("tag", ["std", "star", "inf"])
+def test_general_path_has_the_kernels_semantics(tag):
+    """Problems beyond the expansion kernels' limits (grids over 2048 x 2048, n over 262143) run the host-driven loop with the
+    default cost in numpy form (hostloop.py).  Forced onto a normal-size problem here, with the numpy stand-in for the device
+    primitives, it must give what the kernels' semantics (the oracle) give: graph, goal vertex, costs, generator state, ellipses."""
+    import oracle
+    import orchelp
+    from rrtplanner_amd.oggen import perlin_occupancygrid, random_connected_pair
+
+    og = perlin_occupancygrid(200, 200, seed=1)
+    og8 = oracle.og_u8(og)
+    xs, xg = random_connected_pair(og, np.random.default_rng(3))
+    cls, kw = {"std": (amd.RRTStandard, {}), "star": (amd.RRTStar, dict(r_rewire=25.5)), "inf": (amd.RRTStarInformed, dict(r_rewire=30, r_goal=10))}[tag]
+    p = cls(og, 1500, pbar=False, seed=4, **kw)
+    assert not p._beyond_the_kernels()
+    p._costfn_provider = orchelp.NumpyProvider(og8)
+    p._beyond_the_kernels = lambda: True
+    T, gv = p.plan(xs, xg)
+    q = orchelp.use_oracle(cls(og, 1500, pbar=False, seed=4, **kw))
+    To, go = q.plan(xs, xg)
+    assert gv == go and list(T.nodes) == list(To.nodes) and list(T.edges) == list(To.edges)
+    assert [d["cost"] for *_, d in T.edges(data=True)] == [d["cost"] for *_, d in To.edges(data=True)]
+    assert p.rand_gen.bit_generator.state == q.rand_gen.bit_generator.state
+    if tag == "inf":
+        assert list(p.ellipses) == list(q.ellipses) and len(p.ellipses) > 10
+    big = amd.RRTStar(np.zeros((2049, 10), dtype=int), 10, 5, pbar=False)
+    assert big._beyond_the_kernels() and amd.RRTStar(np.zeros((10, 10), dtype=int), 262144, 5, pbar=False)._beyond_the_kernels()
