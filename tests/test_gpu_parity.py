@@ -979,8 +979,12 @@ def test_missing_grid_and_bad_arguments_fail_loudly():
     q, keep = _ffi.make_query(0, 4, (0, 0), (9, 9), np.zeros((4, 2), dtype=np.int32))
     with pytest.raises(_ffi.RRTError):
         ctx.plan(q, 4)  # goal outside the grid
+    ctx.set_grid(np.zeros((4096, 8), dtype=np.uint8))  # fine for the primitives / the host-driven path (up to 32767 cells per axis) ...
+    with pytest.raises(_ffi.RRTError) as e:
+        _ffi.Batch(ctx, 1, 10)  # ... but beyond what the expansion kernels take
+    assert e.value.code == _ffi.RRT_E_UNSUPPORTED
     with pytest.raises(_ffi.RRTError):
-        ctx.set_grid(np.zeros((4096, 8), dtype=np.uint8))
+        ctx.set_grid(np.zeros((32768, 2), dtype=np.uint8))
     ctx.close()
 
 

@@ -8,6 +8,8 @@ export TMPDIR=/tmp
 cd /tmp
 for what in "$@"; do
 case $what in
+smoke)
+    (cd $R && python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1); echo "smoke rc=$?"; tail -n 4 $O/smoke.log ;;
 tests)
     (cd $R && python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1); echo "tests rc=$?"; tail -n 3 $O/gpu_tests.log ;;
 driver)
