@@ -46,7 +46,7 @@ CONFIGS = {
             n=100000, r_rewire=64, r_goal=None, queries=256, rho=8.0, nh=64, grid_seed=3),
 }
 
-DUBINS_F64_OPS = 1150  # f64 operations of one dub_shortest() (include/rrt_dubins.h: 3 sincos, 9 atan2 + 2 acos at ~60 each, 4 sqrt, 6 words), counted from the source
+DUBINS_F64_OPS = 955  # f64 VALU instructions of one dub_shortest() in the gfx950 ISA (static count over all six words, hipcc -O3; 2 043 instructions in all, 12 divisions)
 F64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector f64 (MI355X_MICROARCH.md)
 
 
@@ -374,7 +374,7 @@ def main():
                                                  "model_frac": fl / F64_VALU_PEAK_TFLOPS,
                                                  "dubins_word_evaluations_model": int(ndub), "dubins_word_evaluations_made": int(made),
                                                  "f64_ops_per_evaluation": DUBINS_F64_OPS,
-                                                 "note": "f64 operations per evaluation are counted from the source (include/rrt_dubins.h), not from a counter pass"}
+                                                 "note": "f64 instructions per evaluation: static count in the compiled ISA of dub_shortest (all branches), not a counter pass; a lane-level figure -- most lanes of a word pass are idle, the SIMD is busy: see bound_observed"}
         if world == 1 and not args.no_cpu_baseline:
             if dubins:
                 out["cpu_baseline"] = cpu_baseline_dubins(og8, cfg, dub_inputs, results[0])
