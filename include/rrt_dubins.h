@@ -144,16 +144,20 @@ RRT_DUB_FN void dub_take(dub_path_t *best, int32_t word, double t, double p, dou
     }
 }
 
-RRT_DUB_FN dub_path_t dub_shortest(double x0, double y0, double th0, double x1, double y1, double th1, double rho) {
+/* (s0, c0), (s1, c1): sine and cosine of the two headings (dub_sincos(th0), dub_sincos(th1): a caller with discrete headings keeps
+ * them in a table).  The sines and cosines of alpha = th0 - theta and beta = th1 - theta come from those by the rotation with
+ * (cos theta, sin theta) = (dx, dy) / D, and cos(alpha - beta) from them: no series (round 2 ran three per word). */
+RRT_DUB_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, double s0, double c0, double x1, double y1, double th1, double s1, double c1,
+                                      double rho) {
     const double dx = x1 - x0, dy = y1 - y0;
-    const double d = sqrt(dx * dx + dy * dy) / rho;
+    const double D = sqrt(dx * dx + dy * dy);
+    const double d = D / rho;
     const double theta = dub_mod2pi(dub_atan2(dy, dx));
     const double alpha = dub_mod2pi(th0 - theta), beta = dub_mod2pi(th1 - theta);
-    double sa, ca, sb, cb, sab, cab;
-    dub_sincos(alpha, &sa, &ca);
-    dub_sincos(beta, &sb, &cb);
-    dub_sincos(alpha - beta, &sab, &cab);
-    (void)sab;
+    const double ct = D > 0.0 ? dx / D : 1.0, st = D > 0.0 ? dy / D : 0.0; /* (atan2(0, 0) = 0) */
+    const double sa = s0 * ct - c0 * st, ca = c0 * ct + s0 * st;
+    const double sb = s1 * ct - c1 * st, cb = c1 * ct + s1 * st;
+    const double cab = ca * cb + sa * sb;
     const double dsq = d * d;
     dub_path_t best;
     best.t = best.p = best.q = 0.0;
@@ -213,6 +217,13 @@ RRT_DUB_FN dub_path_t dub_shortest(double x0, double y0, double th0, double x1, 
     }
     best.len = best.len * rho; /* (t + p + q) * rho; stays +inf when no word applied */
     return best;
+}
+
+RRT_DUB_FN dub_path_t dub_shortest(double x0, double y0, double th0, double x1, double y1, double th1, double rho) {
+    double s0, c0, s1, c1;
+    dub_sincos(th0, &s0, &c0);
+    dub_sincos(th1, &s1, &c1);
+    return dub_shortest_sc(x0, y0, th0, s0, c0, x1, y1, th1, s1, c1, rho);
 }
 
 /* ---- points of a path ---------------------------------------------------------------------------------------------- */
@@ -300,7 +311,9 @@ RRT_DUB_FN void dub_advance_sc(double x, double y, double th, double s0, double 
     }
 }
 
-RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const dub_path_t *path, double rho) {
+/* the set-up with the sine and cosine of th0 given (a caller that keeps a table of the discrete headings' values: the same numbers
+ * dub_sincos(th0) returns) */
+RRT_DUB_FN dub_sweep_t dub_sweep_setup_sc(double x0, double y0, double th0, double sn0, double cs0, const dub_path_t *path, double rho) {
     dub_sweep_t s;
     s.x0 = x0;
     s.y0 = y0;
@@ -315,11 +328,18 @@ RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const d
     s.k2 = dub_seg_kind(path->word, 2);
     /* the two junction poses as dub_advance gives them; the sine and cosine of a junction's heading are the ones the advance
      * that reaches it has just evaluated (same argument), so three series serve the whole set-up */
-    dub_sincos(th0, &s.sn0, &s.cs0);
+    s.sn0 = sn0;
+    s.cs0 = cs0;
     dub_advance_sc(0.0, 0.0, th0, s.sn0, s.cs0, s.k0, s.t, &s.x1, &s.y1, &s.th1, &s.sn1, &s.cs1);
     dub_advance_sc(s.x1, s.y1, s.th1, s.sn1, s.cs1, s.k1, s.p, &s.x2, &s.y2, &s.th2, &s.sn2, &s.cs2);
     s.nsamples = (int32_t)floor(path->len / DUB_DS) + 1;
     return s;
+}
+
+RRT_DUB_FN dub_sweep_t dub_sweep_setup(double x0, double y0, double th0, const dub_path_t *path, double rho) {
+    double sn0, cs0;
+    dub_sincos(th0, &sn0, &cs0);
+    return dub_sweep_setup_sc(x0, y0, th0, sn0, cs0, path, rho);
 }
 
 /* grid cell of sample k (arc length k * DUB_DS from the start) */

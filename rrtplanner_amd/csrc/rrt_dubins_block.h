@@ -68,6 +68,7 @@ struct DbLds {
     uint32_t next, lock;                  // ticket counter, retirement lock
     uint32_t fail;                        // a wave waited DB_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
     unsigned long long stat[6];
+    alignas(16) double htab[3][256];  // angle, sine, cosine of the discrete headings (DubCfg::htab)
     unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, [1] retirements that priced younger vertices, [2] those vertices
 };
 
@@ -90,7 +91,13 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     const bool star = D->alg == 4;
     uint8_t *heading = bv.heading + (size_t)q * bv.node_stride;
     const uint8_t *shead = bv.sample_heading + (size_t)q * bv.n_cap;
-    const DubCfg dc{D->rho, D->nh, bv.W, bv.H};
+    for (int h = t; h < D->nh && h < 256; h += TPB) {  // (visible after the barrier behind the fill counts' copy below)
+        const double th = dub_heading(h, D->nh);
+        L.htab[0][h] = th;
+        dub_sincos(th, &L.htab[1][h], &L.htab[2][h]);
+    }
+    DubCfg dc{D->rho, D->nh, bv.W, bv.H};
+    dc.htab = (const RRT_LDS double *)&L.htab[0][0];
     const uint32_t *samples = bv.samples + (size_t)q * bv.n_cap;
     uint32_t *nodes_g = bv.nodes + (size_t)q * bv.node_stride;
     double *vcost = bv.vcost + (size_t)q * bv.node_stride;

@@ -11,9 +11,17 @@ struct DubCfg {
     double rho;  // turning radius, cells
     int nh;      // discrete headings
     int W, H;
+    // optional (LDS, may be null): angle, sine and cosine of every discrete heading, [3][256] -- exactly dub_heading(h, nh) and
+    // dub_sincos of it, evaluated once per launch instead of a division per pose and a series per sweep
+    const RRT_LDS double *htab = nullptr;
 };
 
+__device__ __forceinline__ double dub_heading_dev(int h, const DubCfg &c) { return c.htab ? c.htab[h] : dub_heading(h, c.nh); }
+
 __device__ __forceinline__ dub_path_t dub_between_dev(uint32_t a, int ha, uint32_t b, int hb, const DubCfg &c) {
+    if (c.htab)
+        return dub_shortest_sc((double)ux(a), (double)uy(a), c.htab[ha], c.htab[256 + ha], c.htab[512 + ha], (double)ux(b), (double)uy(b), c.htab[hb],
+                               c.htab[256 + hb], c.htab[512 + hb], c.rho);
     return dub_shortest((double)ux(a), (double)uy(a), dub_heading(ha, c.nh), (double)ux(b), (double)uy(b), dub_heading(hb, c.nh), c.rho);
 }
 
@@ -26,7 +34,8 @@ __device__ __forceinline__ bool dub_sweep_wave(const uint8_t *__restrict__ og, c
         cells = 0;
         return false;
     }
-    const dub_sweep_t s = dub_sweep_setup((double)ux(a), (double)uy(a), dub_heading(ha, c.nh), &path, c.rho);
+    const dub_sweep_t s = c.htab ? dub_sweep_setup_sc((double)ux(a), (double)uy(a), c.htab[ha], c.htab[256 + ha], c.htab[512 + ha], &path, c.rho)
+                                 : dub_sweep_setup((double)ux(a), (double)uy(a), dub_heading(ha, c.nh), &path, c.rho);
     for (int k0 = 0; k0 < s.nsamples; k0 += 128) {
         bool occ[2] = {false, false};
 #pragma unroll
