@@ -19,6 +19,7 @@
 #include "rrt_kernels.h"
 #include "rrt_block.h"
 #include "rrt_dubins_block.h"
+#include "rrt_pipe.h"
 #include "rrt_prims.h"
 
 using namespace rrtdev;
@@ -95,6 +96,7 @@ struct rrt_batch {
     int32_t last_team = 0;      // workers per query of the last launch (1 after a hand-off timed out)
     bool last_inf = false;      // the last launch ran the Informed instantiation
     bool split = false;         // the last launch ran committers and workers as two kernels (RRT_FLAG_SPLIT_COMMIT)
+    bool last_pipe1 = false;    // the last launch ran the barrier-free one-CU kernel (rrt_pipe.h)
     int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
     int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
     int32_t team_want = TEAM_MAX;  // the caller's cap on the team size
@@ -847,6 +849,7 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         // created with stays and the next launch uses it again
         int team = b->one_cu_once ? 1 : b->team;
         bool pipe_shape = b->pipe_team;
+        const bool continuation = b->one_cu_once;  // (of a launch that stopped at a block boundary: the block kernel takes it from there)
         b->one_cu_once = false;
         cu_release(ctx->device, b->claimed_cus);  // (a launch that was never synchronised)
         b->claimed_cus = 0;
@@ -890,6 +893,19 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
             if (d.status == ST_RUNNING && d.alg == 2) inf = true;
         b->last_team = team;
         b->last_inf = inf;
+        b->last_pipe1 = false;
+        if (team == 1 && !inf && !continuation && !(b->flags & RRT_FLAG_NOPIPE1)) {
+            // one CU per query, RRTStandard / RRTStar: the barrier-free pipeline (rrt_pipe.h; static LDS only)
+            b->last_pipe1 = true;
+            b->split = false;
+            hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+            HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
+            hipLaunchKernelGGL(rrt_pipe_kernel, dim3((unsigned)b->Q), dim3(TPB), 0, ctx->stream, v);
+            HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
+            HIPCHK(ctx, hipGetLastError());
+            b->timed = true;
+            return RRT_OK;
+        }
         HIPCHK(ctx, raise_dynamic_lds(ctx->device, block_kernel_of(team, pipe, inf), (int)blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         if (team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
@@ -973,7 +989,7 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
             d.status = ST_RUNNING;
             team_fail = true;
         }
-    if (team_fail && b->team > 1) {
+    if (team_fail && (b->team > 1 || b->last_pipe1)) {
         float ms0 = 0.f;
         (void)hipEventElapsedTime(&ms0, b->ev0, b->ev1);  // the launch that timed out counts in rrt_batch_elapsed_ms
         b->team_fallbacks += 1;
@@ -1018,7 +1034,8 @@ extern "C" int rrt_batch_kernel_name(rrt_batch *b, char *buf, int32_t len) {
     if (b->use_block) {
         const int team = b->last_team > 0 ? b->last_team : b->team;
         const int bsm = team <= 4 ? 16 : 64 / team;
-        if (b->split) snprintf(tmp, sizeof tmp, "rrt_block_work_kernel<%d, %d, false> + rrt_block_commit_kernel<%d, %d, false>", team, bsm, team, bsm);
+        if (b->last_pipe1) snprintf(tmp, sizeof tmp, "rrt_pipe_kernel");
+        else if (b->split) snprintf(tmp, sizeof tmp, "rrt_block_work_kernel<%d, %d, false> + rrt_block_commit_kernel<%d, %d, false>", team, bsm, team, bsm);
         else snprintf(tmp, sizeof tmp, "rrt_expand_block_kernel<%d, %d, %s, %s>", team, bsm, (team > 1 && b->pipe) ? "true" : "false", b->last_inf ? "true" : "false");
     } else if (b->dub_block) {
         snprintf(tmp, sizeof tmp, "rrt_dubins_block_kernel");

@@ -1,86 +1,70 @@
-// rrt_dubins_block.h -- Dubins-RRT / Dubins-RRT* (BASELINE.json configs[4]; no reference counterpart: include/rrt_dubins.h,
-// oracle/dubins_oracle.c) on one CU per query, 16 samples per round.
+// rrt_pipe.h -- RRTStandard / RRTStar (rrt.py:418-437, :498-548) on ONE CU per query without a workgroup barrier in the loop:
+// the many-query shape (every query of a batch on its own CU; 128 queries and more per GPU, RRT_FLAG_NOTEAM, or a launch that other
+// launches left no room for teams).
 //
-// The loop is the reference's (rrt.py:418-437 / :498-548) with the straight edge replaced by the shortest Dubins word: nearest
-// vertex on (x, y), sweep of the word nearest -> sample, accept test, choose parent over the radius ball, insert.  What is
-// expensive here is the word itself (~1150 dependent f64 operations), so the kernel is built around evaluating few of them:
+// The same pipeline as rrt_dubins_block.h, with the straight edge of the reference: the 16 waves each take the next sample off a
+// ticket counter and resolve it against the tree AS OF A SNAPSHOT (vertices [0, j_snap): the cell records carry the vertex index,
+// younger ones are skipped), deposit the result in a ring in LDS and go on, at most PP_WIN samples ahead of retirement.  Samples
+// RETIRE in order under a lock: a sample is checked, one lane per sample, against the samples inserted since its snapshot -- a
+// younger vertex inside its ball that is cheaper than the chosen parent is tested right there (one line of sight), a younger
+// vertex nearer than the snapshot nearest sends the sample back to be resolved against the exact tree -- then inserted or
+// rejected.  Results equal the sequential loop (and the block kernel's, rrt_block.h, which keeps the Informed planner and the teams).
 //
-//   pipeline  the sample stream does not depend on the tree, so the 16 waves of the workgroup each take the next sample off a
-//             ticket counter and resolve it on their own against the tree AS OF A SNAPSHOT (vertices [0, j_snap): the records
-//             carry the vertex index, younger ones are skipped), deposit the result in a ring in LDS and go on with the next
-//             ticket, at most DB_WIN samples ahead of retirement.  Samples RETIRE in order (whichever wave finds the head of
-//             the ring ready takes a lock and retires as far as it can): a sample is checked against the samples inserted since
-//             its snapshot -- one lane each -- and inserted or rejected if none of them can have influenced it; otherwise the
-//             retiring wave resolves it again, now against the exact tree (it is the head: nothing is in flight before it).
-//             No workgroup barrier in the loop: a sample that needs a second pass delays retirement, not the other waves.
-//             Results equal the sequential loop.
-//   nearest   every vertex also lives as a 16-byte record {xy, index, vcost} in the array of its cell of a uniform cell grid
-//             (the RRT* kernels' layout, rrt_block.h).  A wave streams the records of the cells its sample's radius ball touches
-//             as one packed stream; the nearest record of the box is near()[0] of the whole tree whenever it is no farther
-//             than the box radius (everything outside the box is), else the box is doubled.
-//   chord bound  a Dubins word is never shorter than the chord between its end points, so vcost[v] + |v - x| bounds the cost
-//             through v from below (oracle/dubins_oracle.c counts violations of the slackened bound in its study mode: none).
-//             The walk of rrt.py:515-521 ends at the (cost, index)-smallest visible entry below the cost through the nearest
-//             vertex; an entry whose bound is not below the best visible cost found so far can neither beat nor tie it (the
-//             bounds used are strictly below the computed costs), so it is never priced.  On BASELINE configs[4] 2.6 % of the
-//             near-set entries are priced (4 per accepted sample instead of 157).
-//   pass 1    the first stream leaves in every lane the entry with the smallest bound among the records that lane saw; those
-//             64 entries -- one of them replaced by the nearest vertex -- are priced in ONE word evaluation per lane, the
-//             nearest vertex's word is swept (accept test), and the priced entries below the cost through it are swept in
-//             (cost, index) order until one is visible.
-//   pass 2    only if some lane saw a second entry whose bound is below the best cost so far: the stream runs again, entries
-//             with a bound below the (tightening) best cost are collected in LDS and priced 64 at a time.
+//   resolve   one stream of the records of the cells the radius ball touches: nearest vertex (near()[0], rrt.py:150-155), |within|
+//             (:176-181), and per lane the entry with the smallest single-precision lower bound of cost = vcost + sqrt(d2); the 64
+//             lane minima are priced exactly (f64, sqrt_u24) and tried in (cost, index) order below the cost through the nearest
+//             vertex until one has a free line of sight (choose parent, :511-521); only if some lane saw a second entry whose
+//             bound is below the best cost so far does the stream run again, collecting such entries in LDS, 64 at a time.
 #pragma once
 
-#include "rrt_kernels.h"
+#include "rrt_block.h"
 
 namespace rrtdev {
 
-constexpr int DB_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
-constexpr int DB_WIN = 64;   // samples in flight ahead of retirement
-constexpr unsigned long long DB_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
-constexpr int DB_RING = 128; // ring of deposited / retired samples (>= 2 * DB_WIN: a retiring sample looks back at most DB_WIN - 1,
-                             // the youngest sample in flight is at most DB_WIN - 1 ahead of the head)
+constexpr int PP_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
+constexpr int PP_WIN = 64;   // samples in flight ahead of retirement
+constexpr unsigned long long PP_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
+constexpr int PP_RING = 128; // ring of deposited / retired samples (>= 2 * PP_WIN: a retiring sample looks back at most PP_WIN - 1,
+                             // the youngest sample in flight is at most PP_WIN - 1 ahead of the head)
 
 // One sample as its wave resolved it against its snapshot of the tree (64 bytes); after retirement flags bit 2 says whether it
 // was inserted and cb is its vertex cost (what younger samples in flight are checked against).
-struct DbRec {
-    uint32_t xq, hq;
+struct PpRec {
+    uint32_t xq, pad0;
     uint32_t nn_idx, nn_d2;  // nearest vertex of the snapshot
-    uint32_t flags;          // bit 0: its word's sweep is free, bit 1: the sample's cell is already in `sampled`, bit 2: inserted (retired)
-    uint32_t cells_nn;       // samples of that sweep read
+    uint32_t flags;          // bit 0: free line of sight from it, bit 1: the sample's cell is already in `sampled`, bit 2: inserted (retired)
+    uint32_t cells_nn;       // cells of that line of sight read
     uint32_t hits;           // |within| over the snapshot (RRT*)
     uint32_t vb;             // parent
     double cb;               // cost through the parent
-    uint32_t n_los, cells_cand, nwords;
+    uint32_t n_los, cells_cand, pad1;
     uint32_t snap_i;         // samples retired when it was resolved: it has seen exactly the samples before this one
-    uint32_t ready;          // sample number + 1 once deposited (a slot is reused every DB_RING samples)
+    uint32_t ready;          // sample number + 1 once deposited (a slot is reused every PP_RING samples)
     uint32_t vidx;           // after retirement: its vertex
 };
-static_assert(sizeof(DbRec) == 64, "DbRec");
+static_assert(sizeof(PpRec) == 64, "PpRec");
 
-struct DbLds {
+struct PpLds {
     alignas(16) uint32_t cellcnt[MAX_CELLS];  // live fill counts of the cells; go2goal's two 8 KiB tables afterwards
-    alignas(16) u32x4 buf[NWAVE][DB_BUF];     // pass 2: collected entries {xy, index, vcost}
-    alignas(16) DbRec ring[DB_RING];
+    alignas(16) u32x4 buf[NWAVE][PP_BUF];     // pass 2: collected entries {xy, index, vcost}
+    alignas(16) PpRec ring[PP_RING];
     alignas(16) BSlot bslots[2 * NWAVE];
     alignas(8) unsigned long long state;  // samples retired << 32 | vertices: ONE word, so that a snapshot is consistent
     uint32_t next, lock;                  // ticket counter, retirement lock
-    uint32_t fail;                        // a wave waited DB_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
-    unsigned long long stat[6];
-    alignas(16) double htab[3][256];  // angle, sine, cosine of the discrete headings (DubCfg::htab)
+    uint32_t fail;                        // a wave waited PP_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
+    unsigned long long stat[5];
     unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, [1] retirements that priced younger vertices, [2] those vertices
 };
 
-// conservative single-precision lower bound of vcost + chord (see the head comment): below the f64 value by more than every
-// rounding on the way, for costs up to ~1e5 cells
-__device__ __forceinline__ float db_lower_bound(double V, uint32_t d2) {
+// conservative single-precision lower bound of vcost + sqrt(d2): below the f64 value by more than every rounding on the way, for
+// costs up to ~1e5 cells (the same margins as the block kernel's screens, rrt_block.h)
+__device__ __forceinline__ float pp_lower_bound(double V, uint32_t d2) {
     const float s = ((float)V + __builtin_amdgcn_sqrtf((float)d2)) * (1.0f - 1.0e-6f) - 4.0e-3f;
     return s > 0.0f ? s : 0.0f;
 }
 
-__global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
-    __shared__ DbLds L;
+__global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
+    __shared__ PpLds L;
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     const int q = (int)blockIdx.x;
     QDesc *D = bv.desc + q;
@@ -88,16 +72,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
 
     // ---- per-query views ----
     const int n = D->n;
-    const bool star = D->alg == 4;
-    uint8_t *heading = bv.heading + (size_t)q * bv.node_stride;
-    const uint8_t *shead = bv.sample_heading + (size_t)q * bv.n_cap;
-    for (int h = t; h < D->nh && h < 256; h += TPB) {  // (visible after the barrier behind the fill counts' copy below)
-        const double th = dub_heading(h, D->nh);
-        L.htab[0][h] = th;
-        dub_sincos(th, &L.htab[1][h], &L.htab[2][h]);
-    }
-    DubCfg dc{D->rho, D->nh, bv.W, bv.H};
-    dc.htab = (const RRT_LDS double *)&L.htab[0][0];
+    const bool star = D->alg >= 1;
     const uint32_t *samples = bv.samples + (size_t)q * bv.n_cap;
     uint32_t *nodes_g = bv.nodes + (size_t)q * bv.node_stride;
     double *vcost = bv.vcost + (size_t)q * bv.node_stride;
@@ -113,7 +88,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     u32x4 *cellrec = reinterpret_cast<u32x4 *>(bv.cellrec) + (size_t)q * (size_t)bv.rec_stride;
     uint32_t *cellcnt_g = bv.cellcnt + (size_t)q * (size_t)MAX_CELLS;
     RRT_LDS uint32_t *cellcnt = (RRT_LDS uint32_t *)L.cellcnt;
-    // radius of the first record stream: the rewire radius, but at least two cells (Dubins-RRT has no near set, and a tiny
+    // radius of the first record stream: the rewire radius, but at least two cells (RRTStandard has no near set, and a tiny
     // radius would leave the nearest-vertex search to the doubling below)
     int rad0 = 0;
     {
@@ -125,9 +100,9 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     }
 
     int i = D->i, j = D->j;
-    if (t < 6) L.stat[t] = 0ull;  // statistics: added to by whoever retires (under the lock)
+    if (t < 5) L.stat[t] = 0ull;  // statistics: added to by whoever retires (under the lock)
     if (t < 8) L.dbg[t] = 0ull;
-    if (t < DB_RING) L.ring[t].ready = 0u;
+    if (t < PP_RING) L.ring[t].ready = 0u;
     if (t == 0) {
         L.state = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)j;
         L.next = (uint32_t)i;
@@ -200,22 +175,10 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
         }
     };
 
-    // a word (uniform after the call): the five values of lane `src`
-    auto bcast_path = [&](const dub_path_t &p, int src) -> dub_path_t {
-        dub_path_t o;
-        o.t = __shfl(p.t, src);
-        o.p = __shfl(p.p, src);
-        o.q = __shfl(p.q, src);
-        o.len = __shfl(p.len, src);
-        o.word = __shfl(p.word, src);
-        return o;
-    };
-
-    // Sweep the priced entries of this wave (lane: has, cost cn through vertex idx at a / ha by word pth) that can still become
-    // the parent, cheapest first, until one is visible (rrt.py:515-521 ends at the (cost, index)-smallest visible entry below the
-    // cost through the nearest vertex; `vb == NONE` while the nearest vertex, which wins every tie, is the parent).
-    auto test_priced = [&](bool has, double cn, uint32_t idx, uint32_t a, int ha, const dub_path_t &pth, uint32_t xq, double &cb, uint32_t &vb,
-                           uint32_t &nlos, uint32_t &ccells) {
+    // Test the priced entries of this wave (lane: has, cost cn through vertex idx at a) that can still become the parent,
+    // cheapest first, until one is visible (rrt.py:515-521 ends at the (cost, index)-smallest visible entry below the cost
+    // through the nearest vertex; `vb == NONE` while the nearest vertex, which wins every tie, is the parent).
+    auto test_priced = [&](bool has, double cn, uint32_t idx, uint32_t a, uint32_t xq, double &cb, uint32_t &vb, uint32_t &nlos, uint32_t &ccells) {
         bool open = has;
         for (;;) {
             const bool better = open && (cn < cb || (cn == cb && vb != NONE && idx < vb));
@@ -225,11 +188,9 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             if (ix == NONE) break;
             const unsigned long long m = __ballot(better && idx == ix);
             const int src = (int)__builtin_ctzll(m);
-            const dub_path_t p = bcast_path(pth, src);
-            const uint32_t pa = (uint32_t)__shfl((int)a, src);
-            const int pha = __shfl(ha, src);
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)a, src);
             int cc = 0;
-            const bool ok = dub_sweep_wave(og, dc, pa, pha, xq, p, lane, cc);  // rrt.py:519
+            const bool ok = los_wave(og, H, pa, xq, lane, cc);  // rrt.py:519
             nlos += 1;
             ccells += (uint32_t)cc;
             if (ok) {
@@ -265,7 +226,16 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             auto publish = [&]() {
                 if (h == h0 && npend == 0) return;
                 if (npend > 0) {
+#ifdef RRT_STAMPS
+                    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RRT_STAMPS
+                    if (lane == 0) {
+                        L.dbg[3] += __builtin_amdgcn_s_memtime() - tw0;
+                        L.dbg[4] += 1;
+                    }
+#endif
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane < npend) __hip_atomic_fetch_add(&cellcnt[pend_cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -276,19 +246,18 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             };
             for (;;) {
                 if (h >= n) break;
-                DbRec *slot = &L.ring[h & (DB_RING - 1)];
+                PpRec *slot = &L.ring[h & (PP_RING - 1)];
                 if (__hip_atomic_load(&slot->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) break;
-                DbRec r = *slot;
-                // against the samples inserted since its snapshot: lane l <-> sample snap_i + l (fewer than DB_WIN of them)
+                PpRec r = *slot;
+                // against the samples inserted since its snapshot: lane l <-> sample snap_i + l (fewer than PP_WIN of them)
                 const int m = (int)r.snap_i + lane;
                 bool ins = false;
-                uint32_t xm = 0, hm = 0, vm = NONE;
+                uint32_t xm = 0, vm = NONE;
                 double cm = 0.0;
                 if (m < h) {
-                    const DbRec *e = &L.ring[m & (DB_RING - 1)];
+                    const PpRec *e = &L.ring[m & (PP_RING - 1)];
                     ins = (e->flags & 4u) != 0u;
                     xm = e->xq;
-                    hm = e->hq;
                     vm = e->vidx;
                     cm = e->cb;
                 }
@@ -304,32 +273,23 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 }
                 const unsigned long long same = __ballot(ins && xm == r.xq);
                 const unsigned long long inball = __ballot(ins && star && d2 < r2);
-                uint32_t add_los = 0, add_cells = 0, add_words = 0;
+                uint32_t add_los = 0, add_cells = 0;
                 if (pre_ok && same == 0ull) {
-                    // A younger vertex inside the ball is one more candidate parent (rrt.py:515-521 walks it too) unless its chord
-                    // bound is not below the chosen cost: price those, one word per lane, and sweep the ones below it (a younger
-                    // vertex loses every tie: higher index than the snapshot's choice)
-                    const bool cnd = ins && star && d2 < r2 && cm + sqrt_u32(d2) * (1.0 - 1.0e-9) < r.cb;
+                    // A younger vertex inside the ball is one more candidate parent (rrt.py:515-521 walks it too): the ones below
+                    // the chosen cost are tested, cheapest first (a younger vertex loses every tie against the snapshot's choice:
+                    // higher index)
+                    const double wcn = cm + sqrt_u24(d2);
+                    const bool cnd = ins && star && d2 < r2 && wcn < r.cb;
                     if (__ballot(cnd) != 0ull) {
-                        dub_path_t wp;
-                        wp.t = wp.p = wp.q = 0.0;
-                        wp.len = f64_inf();
-                        wp.word = DUB_NONE;
-                        double wcn = f64_inf();
-                        if (cnd) {
-                            wp = dub_between_dev(xm, (int)hm, r.xq, (int)r.hq, dc);
-                            wcn = cm + wp.len;
-                        }
-                        add_words = (uint32_t)__builtin_popcountll(__ballot(cnd));
 #ifdef RRT_STAMPS
                         if (lane == 0) {
                             L.dbg[1] += 1;
-                            L.dbg[2] += add_words;
+                            L.dbg[2] += (uint32_t)__builtin_popcountll(__ballot(cnd));
                         }
 #endif
                         double cb = r.cb;
                         uint32_t vb = r.vb;
-                        test_priced(cnd, wcn, vm, xm, (int)hm, wp, r.xq, cb, vb, add_los, add_cells);
+                        test_priced(cnd, wcn, vm, xm, r.xq, cb, vb, add_los, add_cells);
                         r.cb = cb;
                         r.vb = vb;
                     }
@@ -345,7 +305,6 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 if (lane == 0) {
                     L.stat[0] += (unsigned long long)jh;
                     L.stat[1] += (unsigned long long)r.cells_nn;
-                    L.stat[5] += (unsigned long long)(r.nwords + add_words);
                     if (logs) {
                         bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)r.nn_idx;
                         bv.accept_log[(size_t)q * bv.n_cap + h] = (uint8_t)acc;
@@ -359,7 +318,6 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                             L.stat[3] += (unsigned long long)(r.cells_cand + add_cells);
                         }
                         nodes_g[jh] = r.xq;
-                        heading[jh] = (uint8_t)r.hq;
                         vcost[jh] = r.cb;
                         parent[jh] = (int32_t)r.vb;
                         const uint32_t cellb = (uint32_t)ux(r.xq) * (uint32_t)H + (uint32_t)uy(r.xq);
@@ -391,7 +349,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
 #endif
             if (redo >= 0) return redo;
             // a deposit that arrived while the lock was held found it taken and left: look at the head once more
-            if (h >= n || __hip_atomic_load(&L.ring[h & (DB_RING - 1)].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) return -1;
+            if (h >= n || __hip_atomic_load(&L.ring[h & (PP_RING - 1)].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) return -1;
         }
     };
 
@@ -412,12 +370,12 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             }
             const int done = (int)(__hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
             if (mine >= n && done >= n) break;
-            if (mine >= n || mine - done >= DB_WIN) {  // nothing left to take, or too far ahead of retirement: help retiring, wait
+            if (mine >= n || mine - done >= PP_WIN) {  // nothing left to take, or too far ahead of retirement: help retiring, wait
                 if (__hip_atomic_load(&L.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;
                 if (done != wait_done) {
                     wait_done = done;
                     wait_t0 = wall_clock64();
-                } else if (wall_clock64() - wait_t0 > DB_STALL_TICKS) {
+                } else if (wall_clock64() - wait_t0 > PP_STALL_TICKS) {
                     if (lane == 0) __hip_atomic_store(&L.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
                 }
@@ -434,7 +392,6 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             const unsigned long long snap = __hip_atomic_load(&L.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t snap_i = (uint32_t)(snap >> 32), jsnap = (uint32_t)snap;
             const uint32_t xq = samples[s];
-            const int hq = (int)shead[s];
             const uint32_t cell = (uint32_t)ux(xq) * (uint32_t)H + (uint32_t)uy(xq);
             const uint32_t bm_word = __hip_atomic_load(bitmap + (cell >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (set by an L2 atomic: read it there)
             // ---- pass 1 of the record stream: nearest record of the box, |within|, per lane the entry with the smallest bound ----
@@ -454,7 +411,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 const bool hit = d2 < r2;  // within(), rrt.py:176-181 (d2 == NONE for a dead lane: never below r2 <= 2^24)
                 hits += hit ? 1u : 0u;
                 const double V = __longlong_as_double((long long)(((unsigned long long)rc.w << 32) | rc.z));
-                const float lb = hit ? db_lower_bound(V, d2) : FINF;
+                const float lb = hit ? pp_lower_bound(V, d2) : FINF;
                 const bool first = lb < m1f || (lb == m1f && hit && rc.y < m1idx);
                 m2f = first ? m1f : __builtin_fminf(m2f, lb);
                 m1f = first ? lb : m1f;
@@ -514,33 +471,20 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             uint32_t e_idx = (lane == slot) ? nn_idx : m1idx;  // the vertex this lane prices (NONE: none)
             const uint32_t e_xy = (lane == slot) ? nn_xy : m1xy;
             const double e_V = __longlong_as_double((long long)(((unsigned long long)((lane == slot) ? nn_vh : m1vh) << 32) | ((lane == slot) ? nn_vl : m1vl)));
-            // ---- one word per lane ----
-            int e_h = 0;
-            dub_path_t e_p;
-            e_p.t = e_p.p = e_p.q = 0.0;
-            e_p.len = f64_inf();
-            e_p.word = DUB_NONE;
-            double e_cn = f64_inf();
-            if (e_idx != NONE) {
-                e_h = (int)heading[e_idx];
-                e_p = dub_between_dev(e_xy, e_h, xq, hq, dc);
-                e_cn = e_V + e_p.len;
-            }
-            uint32_t nwords = (uint32_t)__builtin_popcountll(__ballot(e_idx != NONE));
-            DSTAMP(1);  // one word per lane
-            // ---- nearest vertex: cost through it, its sweep (rrt.py:422-425) ----
-            const dub_path_t p_nn = bcast_path(e_p, slot);
-            const int h_nn = __shfl(e_h, slot);
+            // ---- one exact price per lane ----
+            const double e_cn = e_idx != NONE ? e_V + sqrt_u24(dist2(e_xy, xq)) : f64_inf();
+            DSTAMP(1);  // one price per lane
+            // ---- nearest vertex: cost through it, its line of sight (rrt.py:422-425) ----
             const double c_nn = __shfl(e_cn, slot);
             int cells = 0;
-            const bool nocoll = dub_sweep_wave(og, dc, nn_xy, h_nn, xq, p_nn, lane, cells);
+            const bool nocoll = los_wave(og, H, nn_xy, xq, lane, cells);
             const bool dup = ((bm_word >> (cell & 31)) & 1u) != 0u;
             double cb = c_nn;
             uint32_t vb = NONE, nlos = 0, ccells = 0;
             if (star && nocoll && !dup) {
                 // ---- choose parent: the priced entries, then whatever pass 1 left unpriced below the best cost so far ----
-                test_priced(e_idx != NONE && lane != slot, e_cn, e_idx, e_xy, e_h, e_p, xq, cb, vb, nlos, ccells);
-                DSTAMP(2);  // the nearest vertex's sweep, the sweeps of the priced entries
+                test_priced(e_idx != NONE && lane != slot, e_cn, e_idx, e_xy, xq, cb, vb, nlos, ccells);
+                DSTAMP(2);  // the nearest vertex's line of sight, those of the priced entries
                 if (__ballot((double)left < cb) != 0ull) {
                     RRT_LDS u32x4 *buf = (RRT_LDS u32x4 *)L.buf[wave];
                     uint32_t nbuf = 0;
@@ -549,20 +493,10 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                         u32x4 e = {0u, NONE, 0u, 0u};
                         if ((uint32_t)lane < nbuf) e = buf[lane];
                         const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
-                        bool has = e.y != NONE && (double)db_lower_bound(V, dist2(e.x, xq)) < cb;  // (the best cost may have fallen since the entry was collected)
-                        int fh = 0;
-                        dub_path_t fp;
-                        fp.t = fp.p = fp.q = 0.0;
-                        fp.len = f64_inf();
-                        fp.word = DUB_NONE;
-                        double fcn = f64_inf();
-                        if (has) {
-                            fh = (int)heading[e.y];
-                            fp = dub_between_dev(e.x, fh, xq, hq, dc);
-                            fcn = V + fp.len;
-                        }
-                        nwords += (uint32_t)__builtin_popcountll(__ballot(has));
-                        test_priced(has, fcn, e.y, e.x, fh, fp, xq, cb, vb, nlos, ccells);
+                        const uint32_t fd2 = dist2(e.x, xq);
+                        const bool has = e.y != NONE && (double)pp_lower_bound(V, fd2) < cb;  // (the best cost may have fallen since the entry was collected)
+                        const double fcn = has ? V + sqrt_u24(fd2) : f64_inf();
+                        test_priced(has, fcn, e.y, e.x, xq, cb, vb, nlos, ccells);
                         // drop the 64 entries just handled
                         u32x4 mv = {0u, NONE, 0u, 0u};
                         const bool tail = (uint32_t)lane + 64u < nbuf;
@@ -573,7 +507,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                     stream_box(xq, rad0, jsnap, [&](const u32x4 rc, bool live) {
                         const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                         const double V = __longlong_as_double((long long)(((unsigned long long)rc.w << 32) | rc.z));
-                        const bool take = d2 < r2 && rc.y != nn_idx && rc.y != skip && (double)db_lower_bound(V, d2) < cb;
+                        const bool take = d2 < r2 && rc.y != nn_idx && rc.y != skip && (double)pp_lower_bound(V, d2) < cb;
                         const unsigned long long tm = __ballot(take);
                         if (tm == 0ull) return;
                         if (take) buf[nbuf + (uint32_t)__builtin_popcountll(tm & ((1ull << lane) - 1ull))] = rc;
@@ -581,15 +515,15 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                         if (nbuf >= 64u) flush();
                     });
                     while (nbuf > 0u) flush();
-                    DSTAMP(3);  // pass 2: second stream, its word evaluations and sweeps
+                    DSTAMP(3);  // pass 2: second stream, its prices and lines of sight
                 }
             }
             DSTAMP(2);
             if (lane == 0) {
-                DbRec *slot = &L.ring[s & (DB_RING - 1)];
-                DbRec r;
+                PpRec *slot = &L.ring[s & (PP_RING - 1)];
+                PpRec r;
                 r.xq = xq;
-                r.hq = (uint32_t)hq;
+                r.pad0 = 0u;
                 r.nn_idx = nn_idx;
                 r.nn_d2 = nn_d2;
                 r.flags = (nocoll ? 1u : 0u) | (dup ? 2u : 0u);
@@ -599,7 +533,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 r.cb = cb;
                 r.n_los = nlos;
                 r.cells_cand = ccells;
-                r.nwords = nwords;
+                r.pad1 = 0u;
                 r.snap_i = snap_i;
                 r.ready = 0u;
                 r.vidx = NONE;
@@ -620,13 +554,12 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     for (int k = t; k < ncells; k += TPB) cellcnt_g[k] = cellcnt[k];
     __syncthreads();
     unsigned long long sum_j = D->sum_j, sum_cells_nn = D->sum_cells_nn, sum_near = D->sum_near, sum_cells_cand = D->sum_cells_cand,
-                       n_los_cand = D->n_los_cand, n_words = D->n_words;
+                       n_los_cand = D->n_los_cand;
     sum_j += L.stat[0];
     sum_cells_nn += L.stat[1];
     sum_near += L.stat[2];
     sum_cells_cand += L.stat[3];
     n_los_cand += L.stat[4];
-    n_words += L.stat[5];
     __syncthreads();  // (go2goal reuses the LDS)
 
     // ---------------- go2goal (rrt.py:311-332) ----------------
@@ -636,8 +569,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     } else {
         double pc;
         uint32_t pi;
-        go2goal_phase<true>(og, H, nodes_g, vcost, 0, 1, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)L.cellcnt, L.bslots, t, lane, wave, pc, pi,
-                            heading, D->hg, dc);
+        go2goal_phase<false>(og, H, nodes_g, vcost, 0, 1, j, xg, reinterpret_cast<uint32_t *>(spill), (RRT_LDS uint32_t *)L.cellcnt, L.bslots, t, lane, wave, pc, pi);
         if (pi != NONE) {
             found = 1;
             vgoal = j;
@@ -645,7 +577,6 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 nodes_g[j] = xg;
                 vcost[j] = pc;
                 parent[j] = (int32_t)pi;
-                heading[j] = (uint8_t)D->hg;
             }
         } else {
             if (j < n) status = ST_UNREACHABLE;
@@ -663,7 +594,6 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
         D->sum_near = sum_near;
         D->sum_cells_cand = sum_cells_cand;
         D->n_los_cand = n_los_cand;
-        D->n_words = n_words;
 #ifdef RRT_STAMPS
         for (int k = 0; k < 6; ++k) D->cyc[k] = cyc[k];
         for (int k = 0; k < 8; ++k) D->wcyc[k] = L.dbg[k];

@@ -164,10 +164,12 @@ def test_replan_chain_rng_continues_and_set_og(tag):
 # teams of up to 64 workers per query (default: pipelined, one more CU that only commits), the same without the pipeline, capped
 # teams (2, 3 and 4 workers: 16 samples per member, pipelined and -- 4 -- not; 16: 4 samples per member, 4 waves per sample), one CU,
 # one sample per iteration, and a team that loses a member (must finish on one CU per query)
-KERNELS = ["team", "teamnp", "team2", "team3", "team4", "team4np", "team16", "block", "serial", "teamfault"]
+KERNELS = ["team", "teamnp", "team2", "team3", "team4", "team4np", "team16", "block", "block16", "serial", "teamfault"]
 _KERNEL_ARGS = {"team": {}, "teamnp": {"pipe": False}, "team2": {"team": 2}, "team3": {"team": 3}, "team4": {"team": 4},
                 "team4np": {"team": 4, "pipe": False}, "team16": {"team": 16},
-                "block": {"team": 1}, "serial": {"serial": True}, "teamfault": {"team": 8, "team_fault": True}}
+                # one CU per query: the barrier-free pipeline (rrt_pipe.h; Informed queries run the block kernel), and the block kernel
+                "block": {"team": 1}, "block16": {"team": 1, "pipe1": False},
+                "serial": {"serial": True}, "teamfault": {"team": 8, "team_fault": True}}
 KERNELS_NOFAULT = [k for k in KERNELS if k != "teamfault"]
 
 

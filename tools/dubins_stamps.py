@@ -41,3 +41,5 @@ print("near", r.c.sum_near / n, "los_cand", r.c.n_los_cand / n)
 if not serial:
     print("samples resolved again (a younger vertex nearer than the snapshot nearest): %d (%.2f %%);  retirements that priced younger vertices: %d (%.2f %%), %d words" % (
         cyc[6], 100.0 * cyc[6] / n, cyc[7], 100.0 * cyc[7] / n, cyc[8]))
+    print("lock held %.1f %% of the kernel's cycles: %d times, %.2f samples retired each, %.0f cycles each" % (
+        100.0 * cyc[11] / (ms * 2.4e6), cyc[12], cyc[13] / max(cyc[12], 1), cyc[11] / max(cyc[12], 1)))

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase shader cycles of rrt_pipe_kernel (wave 0 of query 0) from the stamped build.
+
+    make -C rrtplanner_amd/csrc ../librrt_hip_stamps.so
+    RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so python tools/pipe_stamps.py [--n 50000] [--alg 1] [--queries 1] [--grid 1024]
+
+Never quote the stamped build's run time; read the shares."""
+import argparse, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rrtplanner_amd import _ffi, hostprep
+from rrtplanner_amd.oggen import perlin_occupancygrid, random_connected_pair
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=50000)
+ap.add_argument("--alg", type=int, default=1)
+ap.add_argument("--queries", type=int, default=1)
+ap.add_argument("--grid", type=int, default=1024)
+ap.add_argument("--r", type=float, default=64.0)
+a = ap.parse_args()
+og = perlin_occupancygrid(a.grid, a.grid, seed=1)
+free = np.argwhere(og == 0)
+ctx = _ffi.Context(0); ctx.set_grid(hostprep.og_nonzero(og))
+b = _ffi.Batch(ctx, a.queries, a.n, team=1)
+sg = np.random.default_rng(7); keep = []
+for q in range(a.queries):
+    xs, xg = random_connected_pair(og, sg)
+    s = hostprep.draw_free_samples(np.random.default_rng(q), free, a.n)
+    qu, k = _ffi.make_query(a.alg, a.n, xs, xg, s, r2_rewire=hostprep.radius_threshold(a.r)); keep.append(k)
+    b.set_query(q, qu)
+for rep in range(2):
+    b.rearm(); b.launch(); b.sync()
+ms = b.elapsed_ms()
+r = b.get_result(0, arrays=False)
+cyc = b.debug_cycles(0)
+n = a.n
+print(f"kernel {ms:.2f} ms ({b.kernel_name()}), n={n}, nodes={r.c.j}, iters/s={n/ms*1e3:.0f}, status={r.c.status}")
+names = ["first record stream", "one price per lane", "lines of sight (nearest + priced)", "pass 2 (stream, prices, lines)", "waiting (window full / drained)", "deposit + retirement"]
+tot = sum(cyc[:6]) or 1
+for nm, c in zip(names, cyc[:6]): print("  %-34s %12d  %5.1f%%  %8.1f cyc/sample of wave 0" % (nm, c, 100 * c / tot, c * 16 / n))
+print("near %.1f  los_cand %.2f per sample" % (r.c.sum_near / n, r.c.n_los_cand / n))
+print("samples resolved again: %d (%.2f %%);  retirements that tested younger vertices: %d (%.2f %%), %d candidates" % (
+    cyc[6], 100.0 * cyc[6] / n, cyc[7], 100.0 * cyc[7] / n, cyc[8]))
+print("lock held %.1f %% of the kernel's cycles: %d times, %.2f samples retired each, %.0f cycles each; publications %d, %.0f cycles waiting for the stores each" % (
+    100.0 * cyc[11] / (ms * 2.4e6), cyc[12], cyc[13] / max(cyc[12], 1), cyc[11] / max(cyc[12], 1), cyc[10], cyc[9] / max(cyc[10], 1)))
