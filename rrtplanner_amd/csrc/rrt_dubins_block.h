@@ -182,7 +182,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t pre = incl - tcnt;  // lanes past the last cell hold `total`: never <= a live record number
-            for (uint32_t base = 0; base < total; base += 64u) {
+            auto fetch = [&](uint32_t base) -> u32x4 {
                 const uint32_t idx = base + (uint32_t)lane;
                 uint32_t lo = 0;  // the largest cell c with pre[c] <= idx
 #pragma unroll
@@ -193,9 +193,16 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 }
                 const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
                 const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
-                const bool inrange = idx < total;
-                const u32x4 rc = cellrec[inrange ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
-                f(rc, inrange && rc.y < jsnap);
+                return cellrec[idx < total ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
+            };
+            // two steps in flight: the next step's records are requested before this step's are looked at
+            u32x4 rc = {0u, 0u, 0u, 0u};
+            if (total > 0u) rc = fetch(0u);
+            for (uint32_t base = 0; base < total; base += 64u) {
+                u32x4 nx = {0u, 0u, 0u, 0u};
+                if (base + 64u < total) nx = fetch(base + 64u);
+                f(rc, base + (uint32_t)lane < total && rc.y < jsnap);
+                rc = nx;
             }
         }
     };

@@ -50,10 +50,12 @@ struct PpLds {
     alignas(16) PpRec ring[PP_RING];
     alignas(16) BSlot bslots[2 * NWAVE];
     alignas(8) unsigned long long state;  // samples retired << 32 | vertices: ONE word, so that a snapshot is consistent
-    uint32_t next, lock;                  // ticket counter, retirement lock
+    uint32_t next, pad;                   // ticket counter
+    uint32_t simd_of[NWAVE];              // which SIMD each wave runs on
     uint32_t fail;                        // a wave waited PP_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
     unsigned long long stat[5];
-    unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, [1] retirements that priced younger vertices, [2] those vertices
+    unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, [1] retirements that tested younger vertices, [2] those vertices,
+                                // the retiring wave's cycles [3] waiting for the head [4] publishing [5] retiring, [6] heads retired, [7] publications
 };
 
 // conservative single-precision lower bound of vcost + sqrt(d2): below the f64 value by more than every rounding on the way, for
@@ -106,7 +108,6 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     if (t == 0) {
         L.state = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)j;
         L.next = (uint32_t)i;
-        L.lock = 0u;
         L.fail = 0u;
     }
 #ifdef RRT_STAMPS
@@ -127,14 +128,15 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     } while (0)
 #endif
     for (int k = t; k < ncells; k += TPB) cellcnt[k] = cellcnt_g[k];
+    if (lane == 0) L.simd_of[wave] = (__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | ((2 - 1) << 11)) & 3u);  // HW_REG_HW_ID bits [5:4]: SIMD_ID
     __syncthreads();
 
     const float FINF = __uint_as_float(0x7f800000u);
     auto cell_of = [&](uint32_t X) -> int { return (ux(X) >> cshift) * ncy + (uy(X) >> cshift); };
 
     // The records of the cells that the box of half-width `rad` around X touches, as ONE packed stream: lane l of a step takes
-    // record 64 * step + l of the concatenation of the cells' arrays (exclusive prefix sum of the fill counts over the lanes, the
-    // cell of a record by bisection over that prefix with ds_bpermute), 64 cells at a time.  f(record, live) once per step.
+    // record 64 * step + l of the concatenation of the cells' arrays (exclusive prefix sum of the fill counts over the lanes),
+    // 64 cells at a time.  f(record, live) once per step.
     // Records of vertices at or above `jsnap` (inserted after the caller's snapshot) are dealt as dead lanes.
     auto stream_box = [&](uint32_t X, int rad, uint32_t jsnap, auto &&f) {
         const int x = ux(X), y = uy(X);
@@ -156,21 +158,37 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const uint32_t pre = incl - tcnt;  // lanes past the last cell hold `total`: never <= a live record number
-            for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t pre = incl - tcnt;
+            // Which cell a record belongs to, without a search: the non-empty cells are started one after the other as the
+            // stream reaches their first record (lane-uniform walk over the set bits of `rest`; the prefix and the offset of a
+            // cell come by v_readlane), so a step costs a few scalar instructions per cell that begins in it and no LDS traffic.
+            unsigned long long rest = __ballot(tcnt != 0u);
+            uint32_t cur_pre = 0, cur_off = 0;  // the cell that holds the record before this step's first
+            auto fetch = [&](uint32_t base) -> u32x4 {
                 const uint32_t idx = base + (uint32_t)lane;
-                uint32_t lo = 0;  // the largest cell c with pre[c] <= idx
-#pragma unroll
-                for (uint32_t bit = 32; bit != 0; bit >>= 1) {
-                    const uint32_t cand = lo + bit;
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cand << 2), (int)pre);
-                    lo = v <= idx ? cand : lo;
+                uint32_t cpre = cur_pre, coff = cur_off;
+                while (rest != 0ull) {
+                    const int cl = (int)__builtin_ctzll(rest);
+                    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pre, cl);
+                    if (p >= base + 64u) break;
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)toff, cl);
+                    const bool in = idx >= p;
+                    cpre = in ? p : cpre;
+                    coff = in ? o : coff;
+                    cur_pre = p;
+                    cur_off = o;
+                    rest &= rest - 1ull;
                 }
-                const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
-                const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
-                const bool inrange = idx < total;
-                const u32x4 rc = cellrec[inrange ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
-                f(rc, inrange && rc.y < jsnap);
+                return cellrec[idx < total ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
+            };
+            // two steps in flight: the next step's records are requested before this step's are looked at
+            u32x4 rc = {0u, 0u, 0u, 0u};
+            if (total > 0u) rc = fetch(0u);
+            for (uint32_t base = 0; base < total; base += 64u) {
+                u32x4 nx = {0u, 0u, 0u, 0u};
+                if (base + 64u < total) nx = fetch(base + 64u);
+                f(rc, base + (uint32_t)lane < total && rc.y < jsnap);
+                rc = nx;
             }
         }
     };
@@ -202,190 +220,217 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
         }
     };
 
-    // ---- retirement (under the lock): as far as the head of the ring is ready.  Returns the sample number of a head that has to
-    //      be resolved again against the exact tree (its deposit is withdrawn; the caller does it next), else -1. ----
-    auto try_retire = [&]() -> int {
-        for (;;) {
-            uint32_t got = 0;
-            if (lane == 0) got = __hip_atomic_compare_exchange_strong(&L.lock, &got, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
-            if (__builtin_amdgcn_readfirstlane((int)got) == 0) return -1;  // somebody else is retiring; it looks at the head again before it leaves
-#ifndef RRT_NO_RETIRE_PRIO
-            __builtin_amdgcn_s_setprio(3);  // the retirement is the one serial chain of the kernel: ahead of the three waves that share this SIMD
-#endif
-            int redo = -1;
+    // ---- retirement: ONE wave (the last) retires the samples in order and does nothing else, at raised priority: it is the one
+    //      serial chain of the kernel.  The samples inserted or rejected last stay in its REGISTERS (lane m & 63 <-> sample m), so
+    //      that a head is checked against the samples since its snapshot without a pass over the ring; the head's record comes as
+    //      one LDS read (lane k: dword k), the next head's record and the head's cell fill count are in flight meanwhile.
+    //      Returns the number of a head that has to be resolved again against the exact tree (the retiring wave does that itself),
+    //      -1 when everything is retired (or the run failed). ----
+    constexpr int RW = NWAVE - 1;
+    const bool retirer = wave == RW;
+    int rh = i, rj = j, pub_h = i;          // next sample to retire, vertices (the unpublished ones included), samples published
+    uint32_t w_ins = 0u, w_xq = 0u, w_vidx = NONE;  // the window: was sample m inserted, where, as which vertex, at what cost
+    double w_cb = 0.0;
+    uint32_t pend_cell = NONE;  // insertions whose fill counts are not published yet: lane k holds the cell of the k-th
+    int npend = 0;
+    unsigned long long st_j = 0, st_cnn = 0, st_near = 0, st_ccand = 0, st_los = 0;  // statistics (uniform)
+    const RRT_LDS uint32_t *ringw = (const RRT_LDS uint32_t *)&L.ring[0];
 #ifdef RRT_STAMPS
-            const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+    unsigned long long rt_mark = 0, rcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (uniform: scalar registers)
+#define RSTAMP(k)                                                  \
+    do {                                                           \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+        rcyc[k] += now_ - rt_mark;                                 \
+        rt_mark = now_;                                            \
+    } while (0)
+#else
+#define RSTAMP(k) \
+    do {          \
+    } while (0)
 #endif
-            const unsigned long long st0 = __hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            int h = (int)(st0 >> 32), jh = (int)(uint32_t)st0;  // local while the lock is held; published in batches
-            const int h0 = h;
-            // Insertions of this batch whose fill counts are not published yet: lane k holds the cell of the k-th.  The vertices'
-            // stores are acknowledged ONCE per batch (s_waitcnt vmcnt(0)), then the counts and the state name them.
-            uint32_t pend_cell = NONE;
-            int npend = 0;
-            auto publish = [&]() {
-                if (h == h0 && npend == 0) return;
-                if (npend > 0) {
+    // The vertices' stores are acknowledged once per batch (s_waitcnt vmcnt(0)), then the counts and the state name them.
+    auto publish = [&]() {
+        if (rh == pub_h) return;
+        if (npend > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane < npend) __hip_atomic_fetch_add(&cellcnt[pend_cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (lane == 0)
+            __hip_atomic_store(&L.state, ((unsigned long long)(uint32_t)rh << 32) | (uint32_t)rj, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pend_cell = NONE;
+        npend = 0;
+        pub_h = rh;
 #ifdef RRT_STAMPS
-                    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+        rcyc[7] += 1;
 #endif
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto load_rec = [&](int h) -> uint32_t { return ringw[(uint32_t)(h & (PP_RING - 1)) * 16u + (uint32_t)(lane & 15)]; };
+    auto retire = [&]() -> int {
 #ifdef RRT_STAMPS
-                    if (lane == 0) {
-                        L.dbg[3] += __builtin_amdgcn_s_memtime() - tw0;
-                        L.dbg[4] += 1;
-                    }
+        rt_mark = __builtin_amdgcn_s_memtime();
 #endif
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane < npend) __hip_atomic_fetch_add(&cellcnt[pend_cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                if (lane == 0)
-                    __hip_atomic_store(&L.state, ((unsigned long long)(uint32_t)h << 32) | (uint32_t)jh, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pend_cell = NONE;
-                npend = 0;
-            };
-            for (;;) {
-                if (h >= n) break;
-                PpRec *slot = &L.ring[h & (PP_RING - 1)];
-                if (__hip_atomic_load(&slot->ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) break;
-                PpRec r = *slot;
-                // against the samples inserted since its snapshot: lane l <-> sample snap_i + l (fewer than PP_WIN of them)
-                const int m = (int)r.snap_i + lane;
-                bool ins = false;
-                uint32_t xm = 0, vm = NONE;
-                double cm = 0.0;
-                if (m < h) {
-                    const PpRec *e = &L.ring[m & (PP_RING - 1)];
-                    ins = (e->flags & 4u) != 0u;
-                    xm = e->xq;
-                    vm = e->vidx;
-                    cm = e->cb;
-                }
-                const uint32_t d2 = dist2(xm, r.xq);
-                const bool pre_ok = (r.flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before its snapshot
-                if (__ballot(ins && d2 < r.nn_d2) != 0ull) {  // a younger vertex is nearer (it loses ties: higher index): resolve again
-                    if (lane == 0) __hip_atomic_store(&slot->ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    redo = h;
-#ifdef RRT_STAMPS
-                    if (lane == 0) L.dbg[0] += 1;
-#endif
-                    break;
-                }
-                const unsigned long long same = __ballot(ins && xm == r.xq);
-                const unsigned long long inball = __ballot(ins && star && d2 < r2);
-                uint32_t add_los = 0, add_cells = 0;
-                if (pre_ok && same == 0ull) {
-                    // A younger vertex inside the ball is one more candidate parent (rrt.py:515-521 walks it too): the ones below
-                    // the chosen cost are tested, cheapest first (a younger vertex loses every tie against the snapshot's choice:
-                    // higher index)
-                    const double wcn = cm + sqrt_u24(d2);
-                    const bool cnd = ins && star && d2 < r2 && wcn < r.cb;
-                    if (__ballot(cnd) != 0ull) {
-#ifdef RRT_STAMPS
-                        if (lane == 0) {
-                            L.dbg[1] += 1;
-                            L.dbg[2] += (uint32_t)__builtin_popcountll(__ballot(cnd));
-                        }
-#endif
-                        double cb = r.cb;
-                        uint32_t vb = r.vb;
-                        test_priced(cnd, wcn, vm, xm, r.xq, cb, vb, add_los, add_cells);
-                        r.cb = cb;
-                        r.vb = vb;
-                    }
-                }
-                const bool acc = pre_ok && same == 0ull && jh != n;  // rrt.py:425
-                int c = 0;
-                uint32_t pos = 0;
-                if (acc) {
-                    c = cell_of(r.xq);
-                    pos = cellcnt[c] + (uint32_t)__builtin_popcountll(__ballot(pend_cell == (uint32_t)c));
-                    if (lane == npend) pend_cell = (uint32_t)c;
-                }
-                if (lane == 0) {
-                    L.stat[0] += (unsigned long long)jh;
-                    L.stat[1] += (unsigned long long)r.cells_nn;
-                    if (logs) {
-                        bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)r.nn_idx;
-                        bv.accept_log[(size_t)q * bv.n_cap + h] = (uint8_t)acc;
-                        bv.cbest_log[(size_t)q * bv.n_cap + h] = __longlong_as_double(0x7ff8000000000000ll);
-                        bv.j_log[(size_t)q * bv.n_cap + h] = jh;
-                    }
-                    if (acc) {  // rrt.py:524-529
-                        if (star) {
-                            L.stat[2] += (unsigned long long)r.hits + (unsigned long long)__builtin_popcountll(inball);
-                            L.stat[4] += (unsigned long long)(r.n_los + add_los);
-                            L.stat[3] += (unsigned long long)(r.cells_cand + add_cells);
-                        }
-                        nodes_g[jh] = r.xq;
-                        vcost[jh] = r.cb;
-                        parent[jh] = (int32_t)r.vb;
-                        const uint32_t cellb = (uint32_t)ux(r.xq) * (uint32_t)H + (uint32_t)uy(r.xq);
-                        atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
-                        const unsigned long long cbits = (unsigned long long)__double_as_longlong(r.cb);
-                        cellrec[(size_t)c * (size_t)ccap + pos] = u32x4{r.xq, (uint32_t)jh, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
-                    }
-                    // what younger samples in flight are checked against (read under the lock only)
-                    slot->flags = (r.flags & 3u) | (acc ? 4u : 0u);
-                    slot->cb = r.cb;
-                    slot->vidx = (uint32_t)jh;
-                }
-                npend += acc ? 1 : 0;
-                jh += acc ? 1 : 0;
-                h += 1;
-                if (npend == 16) publish();
-            }
+        if (rh >= n) {
             publish();
-#ifdef RRT_STAMPS
-            if (lane == 0) {
-                L.dbg[5] += __builtin_amdgcn_s_memtime() - tl0;
-                L.dbg[6] += 1;
-                L.dbg[7] += (unsigned long long)(h - h0);
+            return -1;
+        }
+        uint32_t rec = load_rec(rh);
+        for (;;) {
+            // ---- the head's record (bounded waiting) ----
+            if ((uint32_t)__builtin_amdgcn_readlane((int)rec, 14) != (uint32_t)rh + 1u) {
+                publish();  // nothing to do: what is retired becomes visible
+                RSTAMP(4);
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    rec = load_rec(rh);
+                    if ((uint32_t)__builtin_amdgcn_readlane((int)rec, 14) == (uint32_t)rh + 1u) break;
+                    if (wall_clock64() - t0 > PP_STALL_TICKS) {  // (never seen; everything retired so far is published above)
+                        if (lane == 0) __hip_atomic_store(&L.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        return -1;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                RSTAMP(3);
             }
+            const int h = rh;
+            const uint32_t xq = (uint32_t)__builtin_amdgcn_readlane((int)rec, 0);
+            const int c = cell_of(xq);
+            const uint32_t ccnt = cellcnt[c];                                    // in flight ...
+            const uint32_t nxt = h + 1 < n ? load_rec(h + 1) : 0u;               // ... with the next head's record
+            const uint32_t nn_idx = (uint32_t)__builtin_amdgcn_readlane((int)rec, 2), nn_d2 = (uint32_t)__builtin_amdgcn_readlane((int)rec, 3);
+            const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)rec, 4), cells_nn = (uint32_t)__builtin_amdgcn_readlane((int)rec, 5);
+            const uint32_t snap_i = (uint32_t)__builtin_amdgcn_readlane((int)rec, 13);
+            uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)rec, 7);
+            double cb = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rec, 9) << 32) |
+                                                         (uint32_t)__builtin_amdgcn_readlane((int)rec, 8)));
+            // against the samples inserted since its snapshot (fewer than PP_WIN): lane l holds the youngest sample m < h with m = l mod 64
+            const uint32_t back = (uint32_t)(h - 1 - lane) & 63u;  // how far behind the head that sample is, less one
+            const bool ins = w_ins != 0u && back < (uint32_t)h - snap_i;
+            const uint32_t d2 = dist2(w_xq, xq);
+            if (__ballot(ins && d2 < nn_d2) != 0ull) {  // a younger vertex is nearer (it loses ties: higher index): resolve again
+#ifdef RRT_STAMPS
+                if (lane == 0) L.dbg[0] += 1;
 #endif
-            if (lane == 0) __hip_atomic_store(&L.lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifndef RRT_NO_RETIRE_PRIO
-            __builtin_amdgcn_s_setprio(0);
+                RSTAMP(5);
+                publish();  // the exact tree: everything retired is visible to the snapshot it takes
+                RSTAMP(4);
+                return h;
+            }
+            const unsigned long long same = __ballot(ins && w_xq == xq);
+            const unsigned long long inball = __ballot(ins && star && d2 < r2);
+            const bool pre_ok = (flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before its snapshot
+            uint32_t add_los = 0, add_cells = 0;
+            if (pre_ok && same == 0ull && inball != 0ull) {
+                // A younger vertex inside the ball is one more candidate parent (rrt.py:515-521 walks it too): the ones below
+                // the chosen cost are tested, cheapest first (a younger vertex loses every tie against the snapshot's choice:
+                // higher index)
+                const double wcn = w_cb + sqrt_u24(d2);
+                const bool cnd = ins && star && d2 < r2 && wcn < cb;
+                if (__ballot(cnd) != 0ull) {
+                    test_priced(cnd, wcn, w_vidx, w_xq, xq, cb, vb, add_los, add_cells);
+                }
+            }
+            const bool acc = pre_ok && same == 0ull && rj != n;  // rrt.py:425
+            RSTAMP(0);
+            st_j += (unsigned long long)rj;
+            st_cnn += (unsigned long long)cells_nn;
+            if (logs && lane == 0) {
+                bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)nn_idx;
+                bv.accept_log[(size_t)q * bv.n_cap + h] = (uint8_t)acc;
+                bv.cbest_log[(size_t)q * bv.n_cap + h] = __longlong_as_double(0x7ff8000000000000ll);
+                bv.j_log[(size_t)q * bv.n_cap + h] = rj;
+            }
+            if (acc) {  // rrt.py:524-529
+                if (star) {
+                    st_near += (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rec, 6) + (unsigned long long)__builtin_popcountll(inball);
+                    st_los += (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)rec, 10) + add_los);
+                    st_ccand += (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)rec, 11) + add_cells);
+                }
+                const uint32_t pos = ccnt + (uint32_t)__builtin_popcountll(__ballot(pend_cell == (uint32_t)c));
+                if (lane == npend) pend_cell = (uint32_t)c;
+                RSTAMP(1);
+                if (lane == 0) {
+                    nodes_g[rj] = xq;
+                    vcost[rj] = cb;
+                    parent[rj] = (int32_t)vb;
+                    const uint32_t cellb = (uint32_t)ux(xq) * (uint32_t)H + (uint32_t)uy(xq);
+                    atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
+                    const unsigned long long cbits = (unsigned long long)__double_as_longlong(cb);
+                    cellrec[(size_t)c * (size_t)ccap + pos] = u32x4{xq, (uint32_t)rj, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+                }
+            }
+            // the window: this sample in its lane
+            if (lane == (h & 63)) {
+                w_ins = acc ? 1u : 0u;
+                w_xq = xq;
+                w_vidx = (uint32_t)rj;
+                w_cb = cb;
+            }
+            npend += acc ? 1 : 0;
+            rj += acc ? 1 : 0;
+            rh = h + 1;
+#ifdef RRT_STAMPS
+            rcyc[6] += 1;
 #endif
-            if (redo >= 0) return redo;
-            // a deposit that arrived while the lock was held found it taken and left: look at the head once more
-            if (h >= n || __hip_atomic_load(&L.ring[h & (PP_RING - 1)].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)h + 1u) return -1;
+            if (npend == 16 || rh - pub_h >= 16) {
+                RSTAMP(5);
+                publish();
+                RSTAMP(4);
+            }
+            if (rh >= n) {
+                RSTAMP(5);
+                publish();
+                RSTAMP(4);
+                return -1;
+            }
+            RSTAMP(2);
+            rec = nxt;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            RSTAMP(5);
         }
     };
+    if (retirer) __builtin_amdgcn_s_setprio(3);
+#ifndef RRT_PIPE_SHARED_SIMD
+    // The retiring wave has its SIMD to itself: the other waves of the workgroup that landed there only join the barriers.  (The
+    // retirement is a chain of ~100 dependent instructions per sample; next to three streaming waves it got one issue slot in
+    // four, wave priority or not, and the twelve other waves waited for it.)
+    const bool idle = !retirer && L.simd_of[wave] == L.simd_of[RW];
+#else
+    const bool idle = false;
+#endif
 
-    int mine = -1, redo = -1;  // a ticket taken but not resolved yet; a head to resolve again (first)
-    int wait_done = -1;        // bounded waiting: the retired count when this wave began to wait, and when
+    int wait_done = -1;  // bounded waiting of a resolving wave: the retired count when it began to wait, and when
     unsigned long long wait_t0 = 0;
-    for (;;) {
+    for (; !idle;) {
         int s;
-        if (redo >= 0) {
-            s = redo;
-            redo = -1;
+        if (retirer) {
+            s = retire();
+            if (s < 0) break;
         } else {
-            if (mine < 0) {
-                uint32_t tk = 0;
-                if (lane == 0) tk = __hip_atomic_fetch_add(&L.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                mine = __builtin_amdgcn_readfirstlane((int)tk);
-                if (mine > n) mine = n;  // (the counter runs on while the waves drain)
-            }
-            const int done = (int)(__hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
-            if (mine >= n && done >= n) break;
-            if (mine >= n || mine - done >= PP_WIN) {  // nothing left to take, or too far ahead of retirement: help retiring, wait
-                if (__hip_atomic_load(&L.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;
+            uint32_t tk = 0;
+            if (lane == 0) tk = __hip_atomic_fetch_add(&L.next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            s = __builtin_amdgcn_readfirstlane((int)tk);
+            if (s >= n) break;
+            bool failed = false;
+            for (;;) {  // not more than PP_WIN samples ahead of retirement
+                const int done = (int)(__hip_atomic_load(&L.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
+                if (s - done < PP_WIN) break;
+                if (__hip_atomic_load(&L.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {
+                    failed = true;
+                    break;
+                }
                 if (done != wait_done) {
                     wait_done = done;
                     wait_t0 = wall_clock64();
                 } else if (wall_clock64() - wait_t0 > PP_STALL_TICKS) {
                     if (lane == 0) __hip_atomic_store(&L.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    failed = true;
                     break;
                 }
-                redo = try_retire();
-                if (redo < 0) __builtin_amdgcn_s_sleep(16);
-                DSTAMP(4);  // (diagnostic build, wave 0) waiting
-                continue;
+                __builtin_amdgcn_s_sleep(16);
             }
-            s = mine;
-            mine = -1;
+            DSTAMP(4);  // (diagnostic build, wave 0) waiting
+            if (failed) break;
         }
         // =============================== resolve sample s against a snapshot ===============================
         {
@@ -541,8 +586,25 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                 __hip_atomic_store(&slot->ready, (uint32_t)s + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-        redo = try_retire();
-        DSTAMP(5);  // deposit + retirement
+        DSTAMP(5);  // deposit
+    }
+    if (retirer) {
+        __builtin_amdgcn_s_setprio(0);
+#ifdef RRT_STAMPS
+        if (lane == 0) {
+            L.dbg[1] = rcyc[0];  // (diagnostic: the three parts of a head instead of the younger-vertex counts)
+            L.dbg[2] = rcyc[1];
+            for (int k = 3; k < 8; ++k) L.dbg[k] = rcyc[k];
+            L.dbg[3] = rcyc[3] | (rcyc[2] << 40);
+        }
+#endif
+        if (lane == 0) {
+            L.stat[0] = st_j;
+            L.stat[1] = st_cnn;
+            L.stat[2] = st_near;
+            L.stat[3] = st_ccand;
+            L.stat[4] = st_los;
+        }
     }
     __syncthreads();
     {

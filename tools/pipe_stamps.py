@@ -35,11 +35,12 @@ r = b.get_result(0, arrays=False)
 cyc = b.debug_cycles(0)
 n = a.n
 print(f"kernel {ms:.2f} ms ({b.kernel_name()}), n={n}, nodes={r.c.j}, iters/s={n/ms*1e3:.0f}, status={r.c.status}")
-names = ["first record stream", "one price per lane", "lines of sight (nearest + priced)", "pass 2 (stream, prices, lines)", "waiting (window full / drained)", "deposit + retirement"]
+names = ["first record stream", "one price per lane", "lines of sight (nearest + priced)", "pass 2 (stream, prices, lines)", "waiting (window full)", "deposit"]
 tot = sum(cyc[:6]) or 1
-for nm, c in zip(names, cyc[:6]): print("  %-34s %12d  %5.1f%%  %8.1f cyc/sample of wave 0" % (nm, c, 100 * c / tot, c * 16 / n))
+for nm, c in zip(names, cyc[:6]): print("  %-34s %12d  %5.1f%%  %8.1f cyc/sample of wave 0" % (nm, c, 100 * c / tot, c * 15 / n))
 print("near %.1f  los_cand %.2f per sample" % (r.c.sum_near / n, r.c.n_los_cand / n))
-print("samples resolved again: %d (%.2f %%);  retirements that tested younger vertices: %d (%.2f %%), %d candidates" % (
-    cyc[6], 100.0 * cyc[6] / n, cyc[7], 100.0 * cyc[7] / n, cyc[8]))
-print("lock held %.1f %% of the kernel's cycles: %d times, %.2f samples retired each, %.0f cycles each; publications %d, %.0f cycles waiting for the stores each" % (
-    100.0 * cyc[11] / (ms * 2.4e6), cyc[12], cyc[13] / max(cyc[12], 1), cyc[11] / max(cyc[12], 1), cyc[10], cyc[9] / max(cyc[10], 1)))
+print("samples resolved again: %d (%.2f %%)" % (cyc[6], 100.0 * cyc[6] / n))
+wait_head, stores = cyc[9] & ((1 << 40) - 1), cyc[9] >> 40
+tot_r = (wait_head + cyc[10] + cyc[11] + cyc[7] + cyc[8] + stores) or 1
+print("the retiring wave: waiting for the head %.1f %%, publishing %.1f %% (%d publications, %.0f cycles each); %d heads: checks %.0f, position %.0f, stores + window %.0f, next record %.0f cycles each" % (
+    100.0 * wait_head / tot_r, 100.0 * cyc[10] / tot_r, cyc[13], cyc[10] / max(cyc[13], 1), cyc[12], cyc[7] / max(cyc[12], 1), cyc[8] / max(cyc[12], 1), stores / max(cyc[12], 1), cyc[11] / max(cyc[12], 1)))

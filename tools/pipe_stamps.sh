@@ -3,5 +3,4 @@ O=gpurun_out/r03; mkdir -p $O
 make -C rrtplanner_amd/csrc ../librrt_hip_stamps.so > /dev/null 2>&1; echo "stamps build rc=$?"
 RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so timeout -k 10 300 python3 tools/pipe_stamps.py > $O/pipe_stamps.txt 2>&1
 RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so timeout -k 10 300 python3 tools/pipe_stamps.py --n 20000 --queries 64 >> $O/pipe_stamps.txt 2>&1
-RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so timeout -k 10 300 python3 tools/pipe_stamps.py --alg 0 >> $O/pipe_stamps.txt 2>&1
 cat $O/pipe_stamps.txt
