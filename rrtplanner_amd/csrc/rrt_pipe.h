@@ -2,19 +2,29 @@
 // the many-query shape (every query of a batch on its own CU; 128 queries and more per GPU, RRT_FLAG_NOTEAM, or a launch that other
 // launches left no room for teams).
 //
-// The same pipeline as rrt_dubins_block.h, with the straight edge of the reference: the 16 waves each take the next sample off a
-// ticket counter and resolve it against the tree AS OF A SNAPSHOT (vertices [0, j_snap): the cell records carry the vertex index,
-// younger ones are skipped), deposit the result in a ring in LDS and go on, at most PP_WIN samples ahead of retirement.  Samples
-// RETIRE in order under a lock: a sample is checked, one lane per sample, against the samples inserted since its snapshot -- a
-// younger vertex inside its ball that is cheaper than the chosen parent is tested right there (one line of sight), a younger
-// vertex nearer than the snapshot nearest sends the sample back to be resolved against the exact tree -- then inserted or
-// rejected.  Results equal the sequential loop (and the block kernel's, rrt_block.h, which keeps the Informed planner and the teams).
+// The pipeline of rrt_dubins_block.h with the straight edge of the reference.  Waves resolve samples side by side, each against
+// the tree AS OF A SNAPSHOT (vertices [0, j_snap): the cell records carry the vertex index, younger ones are skipped); ONE wave
+// retires them in order.  Results equal the sequential loop (and the block kernel's, rrt_block.h, which keeps the Informed planner
+// and the teams).
 //
-//   resolve   one stream of the records of the cells the radius ball touches: nearest vertex (near()[0], rrt.py:150-155), |within|
-//             (:176-181), and per lane the entry with the smallest single-precision lower bound of cost = vcost + sqrt(d2); the 64
-//             lane minima are priced exactly (f64, sqrt_u24) and tried in (cost, index) order below the cost through the nearest
-//             vertex until one has a free line of sight (choose parent, :511-521); only if some lane saw a second entry whose
-//             bound is below the best cost so far does the stream run again, collecting such entries in LDS, 64 at a time.
+//   resolve   (12 waves) take the next sample off a ticket counter, at most PP_WIN ahead of retirement.  One stream of the records
+//             of the cells the radius ball touches: nearest vertex (near()[0], rrt.py:150-155), |within| (:176-181), and per lane
+//             the entry with the smallest single-precision lower bound of cost = vcost + sqrt(d2); the 64 lane minima are priced
+//             exactly (f64, sqrt_u24) and tried in (cost, index) order below the cost through the nearest vertex until one has a
+//             free line of sight (choose parent, :511-521); only if some lane saw a second entry whose bound is below the best
+//             cost so far does the stream run again, collecting such entries in LDS, 64 at a time.  The result goes into a ring
+//             in LDS together with four 64-bit masks over the samples still in flight at the snapshot (the sample stream is an
+//             input, rrt.py:240): nearer than the nearest vertex found / on the same grid cell / inside the ball / in the same
+//             record cell.
+//   retire    (1 wave, alone on its SIMD: the three other waves that landed there only join the barriers) the one serial chain of
+//             the kernel, a few scalar operations per sample: the record's masks against the bits of the samples inserted last
+//             decide "resolve again" (a younger vertex is nearer: the retiring wave does it itself, against the exact tree),
+//             "reject" (same grid cell, rrt.py:425), and which younger vertices are further candidate parents (priced and tested
+//             right there).  Insertions are stored 16 at a time; fill counts and state are published behind their acknowledgement.
+//
+// Measured (profiles/r03_experiments.md): the retirement decides the run time as long as it costs more than a twelfth of a
+// resolution; done lane-parallel per sample against a window of the last 64 samples it took ~2000 cycles per sample, next to
+// streaming waves on the same SIMD or not.
 #pragma once
 
 #include "rrt_block.h"
@@ -24,25 +34,37 @@ namespace rrtdev {
 constexpr int PP_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
 constexpr int PP_WIN = 64;   // samples in flight ahead of retirement
 constexpr unsigned long long PP_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
-constexpr int PP_RING = 128; // ring of deposited / retired samples (>= 2 * PP_WIN: a retiring sample looks back at most PP_WIN - 1,
-                             // the youngest sample in flight is at most PP_WIN - 1 ahead of the head)
+constexpr int PP_RING = 64;  // ring of deposited samples (>= PP_WIN: the slot of sample s is written again for s + PP_RING, which is
+                             // only taken once s has been retired)
 
-// One sample as its wave resolved it against its snapshot of the tree (64 bytes); after retirement flags bit 2 says whether it
-// was inserted and cb is its vertex cost (what younger samples in flight are checked against).
+// One sample as its wave resolved it against its snapshot of the tree (128 bytes, 32 words: the retiring wave reads a record with
+// one LDS instruction, lane k word k).  The four masks are over the samples in flight since the snapshot, bit m & 63 for sample m
+// in [snap_i, s): what the retiring wave needs to know about them does not depend on whether they were inserted, so the
+// resolving wave works it out (the sample stream is an input, rrt.py:240) and the retirement is a few scalar operations.
 struct PpRec {
-    uint32_t xq, pad0;
+    uint32_t xq;
     uint32_t nn_idx, nn_d2;  // nearest vertex of the snapshot
-    uint32_t flags;          // bit 0: free line of sight from it, bit 1: the sample's cell is already in `sampled`, bit 2: inserted (retired)
+    uint32_t flags;          // bit 0: free line of sight from it, bit 1: the sample's cell is already in `sampled`
     uint32_t cells_nn;       // cells of that line of sight read
     uint32_t hits;           // |within| over the snapshot (RRT*)
     uint32_t vb;             // parent
+    uint32_t n_los;
     double cb;               // cost through the parent
-    uint32_t n_los, cells_cand, pad1;
+    uint32_t cells_cand;
     uint32_t snap_i;         // samples retired when it was resolved: it has seen exactly the samples before this one
-    uint32_t ready;          // sample number + 1 once deposited (a slot is reused every PP_RING samples)
-    uint32_t vidx;           // after retirement: its vertex
+    uint32_t ready;          // sample number + 1 once deposited
+    uint32_t ccnt;           // records in the sample's cell as of the snapshot
+    uint32_t pad0[2];
+    unsigned long long nnmask;    // samples in flight nearer than the snapshot's nearest vertex
+    unsigned long long dupmask;   // ... on the same grid cell
+    unsigned long long rmask;     // ... within r_rewire (RRT*)
+    unsigned long long cellmask;  // ... in the same cell of the record grid
+    uint32_t pad1[8];
 };
-static_assert(sizeof(PpRec) == 64, "PpRec");
+static_assert(sizeof(PpRec) == 128, "PpRec");
+// word numbers of the fields (the retiring wave's v_readlane)
+constexpr int PW_XQ = 0, PW_NNIDX = 1, PW_NND2 = 2, PW_FLAGS = 3, PW_CELLSNN = 4, PW_HITS = 5, PW_VB = 6, PW_NLOS = 7, PW_CB = 8, PW_CCAND = 10,
+              PW_SNAPI = 11, PW_READY = 12, PW_CCNT = 13, PW_NNMASK = 16, PW_DUPMASK = 18, PW_RMASK = 20, PW_CELLMASK = 22;
 
 struct PpLds {
     alignas(16) uint32_t cellcnt[MAX_CELLS];  // live fill counts of the cells; go2goal's two 8 KiB tables afterwards
@@ -50,12 +72,13 @@ struct PpLds {
     alignas(16) PpRec ring[PP_RING];
     alignas(16) BSlot bslots[2 * NWAVE];
     alignas(8) unsigned long long state;  // samples retired << 32 | vertices: ONE word, so that a snapshot is consistent
-    uint32_t next, pad;                   // ticket counter
-    uint32_t simd_of[NWAVE];              // which SIMD each wave runs on
+    uint32_t next;                        // ticket counter
+    uint32_t pubseq;                      // odd while fill counts and state are being brought up to date (a snapshot reads both)
     uint32_t fail;                        // a wave waited PP_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
+    uint32_t simd_of[NWAVE];              // which SIMD each wave runs on
     unsigned long long stat[5];
-    unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, [1] retirements that tested younger vertices, [2] those vertices,
-                                // the retiring wave's cycles [3] waiting for the head [4] publishing [5] retiring, [6] heads retired, [7] publications
+    unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, the retiring wave's cycles [1] fast path [2] slow path (younger vertices in
+                                // the ball) [3] waiting for the head [4] publishing [5] next record, [6] heads retired, [7] publications
 };
 
 // conservative single-precision lower bound of vcost + sqrt(d2): below the f64 value by more than every rounding on the way, for
@@ -108,6 +131,7 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     if (t == 0) {
         L.state = ((unsigned long long)(uint32_t)i << 32) | (uint32_t)j;
         L.next = (uint32_t)i;
+        L.pubseq = 0u;
         L.fail = 0u;
     }
 #ifdef RRT_STAMPS
@@ -220,18 +244,22 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
         }
     };
 
-    // ---- retirement: ONE wave (the last) retires the samples in order and does nothing else, at raised priority: it is the one
-    //      serial chain of the kernel.  The samples inserted or rejected last stay in its REGISTERS (lane m & 63 <-> sample m), so
-    //      that a head is checked against the samples since its snapshot without a pass over the ring; the head's record comes as
-    //      one LDS read (lane k: dword k), the next head's record and the head's cell fill count are in flight meanwhile.
+    // ---- retirement: ONE wave (the last) retires the samples in order and does nothing else: it is the one serial chain of the
+    //      kernel.  Per sample a handful of scalar operations: the record's masks against the bits of the samples inserted last
+    //      (bit m & 63 <-> sample m) say whether a younger vertex is nearer than the snapshot's nearest (resolve again), sits on
+    //      the same grid cell (reject), or lies in the ball (one more candidate parent: those are priced, lane m & 63 holds the
+    //      sample's position, vertex and cost).  Insertions wait in lanes and are stored 16 at a time; their stores are acknowledged
+    //      once per batch (s_waitcnt vmcnt(0)), then the fill counts and the state name them.
     //      Returns the number of a head that has to be resolved again against the exact tree (the retiring wave does that itself),
     //      -1 when everything is retired (or the run failed). ----
     constexpr int RW = NWAVE - 1;
     const bool retirer = wave == RW;
     int rh = i, rj = j, pub_h = i;          // next sample to retire, vertices (the unpublished ones included), samples published
-    uint32_t w_ins = 0u, w_xq = 0u, w_vidx = NONE;  // the window: was sample m inserted, where, as which vertex, at what cost
+    unsigned long long insbits = 0ull;      // bit m & 63: sample m (one of the last 64) was inserted
+    uint32_t w_xq = 0u, w_vidx = NONE;      // lane m & 63: where, as which vertex, at what cost
     double w_cb = 0.0;
-    uint32_t pend_cell = NONE;  // insertions whose fill counts are not published yet: lane k holds the cell of the k-th
+    uint32_t p_xq = 0u, p_vb = 0u, p_rj = 0u, p_rec = 0u, p_cell = 0u;  // insertions not stored yet: lane k holds the k-th
+    double p_cb = 0.0;
     int npend = 0;
     unsigned long long st_j = 0, st_cnn = 0, st_near = 0, st_ccand = 0, st_los = 0;  // statistics (uniform)
     const RRT_LDS uint32_t *ringw = (const RRT_LDS uint32_t *)&L.ring[0];
@@ -248,24 +276,36 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     do {          \
     } while (0)
 #endif
-    // The vertices' stores are acknowledged once per batch (s_waitcnt vmcnt(0)), then the counts and the state name them.
     auto publish = [&]() {
         if (rh == pub_h) return;
+        if (lane == 0) __hip_atomic_store(&L.pubseq, 2u * (uint32_t)pub_h + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (npend > 0) {
+            if (lane < npend) {  // rrt.py:524-529
+                nodes_g[p_rj] = p_xq;
+                vcost[p_rj] = p_cb;
+                parent[p_rj] = (int32_t)p_vb;
+                const uint32_t cellb = (uint32_t)ux(p_xq) * (uint32_t)H + (uint32_t)uy(p_xq);
+                atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
+                const unsigned long long cbits = (unsigned long long)__double_as_longlong(p_cb);
+                cellrec[p_rec] = u32x4{p_xq, p_rj, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane < npend) __hip_atomic_fetch_add(&cellcnt[pend_cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane < npend) __hip_atomic_fetch_add(&cellcnt[p_cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (lane == 0)
+        if (lane == 0) {
             __hip_atomic_store(&L.state, ((unsigned long long)(uint32_t)rh << 32) | (uint32_t)rj, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        pend_cell = NONE;
+            __hip_atomic_store(&L.pubseq, 2u * (uint32_t)rh, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         npend = 0;
         pub_h = rh;
 #ifdef RRT_STAMPS
         rcyc[7] += 1;
 #endif
     };
-    auto load_rec = [&](int h) -> uint32_t { return ringw[(uint32_t)(h & (PP_RING - 1)) * 16u + (uint32_t)(lane & 15)]; };
+    auto load_rec = [&](int h) -> uint32_t { return ringw[(uint32_t)(h & (PP_RING - 1)) * 32u + (uint32_t)(lane & 31)]; };
+    auto rl = [&](uint32_t v, int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); };
+    auto rl64 = [&](uint32_t v, int k) -> unsigned long long { return ((unsigned long long)rl(v, k + 1) << 32) | rl(v, k); };
     auto retire = [&]() -> int {
 #ifdef RRT_STAMPS
         rt_mark = __builtin_amdgcn_s_memtime();
@@ -275,15 +315,17 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
             return -1;
         }
         uint32_t rec = load_rec(rh);
+        uint32_t nxt = rh + 1 < n ? load_rec(rh + 1) : 0u;
         for (;;) {
             // ---- the head's record (bounded waiting) ----
-            if ((uint32_t)__builtin_amdgcn_readlane((int)rec, 14) != (uint32_t)rh + 1u) {
+            if (rl(rec, PW_READY) != (uint32_t)rh + 1u) {
                 publish();  // nothing to do: what is retired becomes visible
                 RSTAMP(4);
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
                     rec = load_rec(rh);
-                    if ((uint32_t)__builtin_amdgcn_readlane((int)rec, 14) == (uint32_t)rh + 1u) break;
+                    nxt = rh + 1 < n ? load_rec(rh + 1) : 0u;
+                    if (rl(rec, PW_READY) == (uint32_t)rh + 1u) break;
                     if (wall_clock64() - t0 > PP_STALL_TICKS) {  // (never seen; everything retired so far is published above)
                         if (lane == 0) __hip_atomic_store(&L.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         return -1;
@@ -293,100 +335,90 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                 RSTAMP(3);
             }
             const int h = rh;
-            const uint32_t xq = (uint32_t)__builtin_amdgcn_readlane((int)rec, 0);
-            const int c = cell_of(xq);
-            const uint32_t ccnt = cellcnt[c];                                    // in flight ...
-            const uint32_t nxt = h + 1 < n ? load_rec(h + 1) : 0u;               // ... with the next head's record
-            const uint32_t nn_idx = (uint32_t)__builtin_amdgcn_readlane((int)rec, 2), nn_d2 = (uint32_t)__builtin_amdgcn_readlane((int)rec, 3);
-            const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)rec, 4), cells_nn = (uint32_t)__builtin_amdgcn_readlane((int)rec, 5);
-            const uint32_t snap_i = (uint32_t)__builtin_amdgcn_readlane((int)rec, 13);
-            uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)rec, 7);
-            double cb = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rec, 9) << 32) |
-                                                         (uint32_t)__builtin_amdgcn_readlane((int)rec, 8)));
-            // against the samples inserted since its snapshot (fewer than PP_WIN): lane l holds the youngest sample m < h with m = l mod 64
-            const uint32_t back = (uint32_t)(h - 1 - lane) & 63u;  // how far behind the head that sample is, less one
-            const bool ins = w_ins != 0u && back < (uint32_t)h - snap_i;
-            const uint32_t d2 = dist2(w_xq, xq);
-            if (__ballot(ins && d2 < nn_d2) != 0ull) {  // a younger vertex is nearer (it loses ties: higher index): resolve again
+            const uint32_t nx2 = h + 2 < n ? load_rec(h + 2) : 0u;  // the records of the next two heads are in flight meanwhile
+            const uint32_t xq = rl(rec, PW_XQ), flags = rl(rec, PW_FLAGS);
+            if ((rl64(rec, PW_NNMASK) & insbits) != 0ull) {  // a younger vertex is nearer (it loses ties: higher index): resolve again
 #ifdef RRT_STAMPS
                 if (lane == 0) L.dbg[0] += 1;
 #endif
-                RSTAMP(5);
+                RSTAMP(1);
                 publish();  // the exact tree: everything retired is visible to the snapshot it takes
                 RSTAMP(4);
                 return h;
             }
-            const unsigned long long same = __ballot(ins && w_xq == xq);
-            const unsigned long long inball = __ballot(ins && star && d2 < r2);
             const bool pre_ok = (flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before its snapshot
+            const bool dup = (rl64(rec, PW_DUPMASK) & insbits) != 0ull;
+            const unsigned long long inball = rl64(rec, PW_RMASK) & insbits;
+            uint32_t vb = rl(rec, PW_VB);
+            double cb = __longlong_as_double((long long)rl64(rec, PW_CB));
             uint32_t add_los = 0, add_cells = 0;
-            if (pre_ok && same == 0ull && inball != 0ull) {
+            bool slow = false;
+            if (pre_ok && !dup && inball != 0ull) {
                 // A younger vertex inside the ball is one more candidate parent (rrt.py:515-521 walks it too): the ones below
                 // the chosen cost are tested, cheapest first (a younger vertex loses every tie against the snapshot's choice:
                 // higher index)
-                const double wcn = w_cb + sqrt_u24(d2);
-                const bool cnd = ins && star && d2 < r2 && wcn < cb;
-                if (__ballot(cnd) != 0ull) {
-                    test_priced(cnd, wcn, w_vidx, w_xq, xq, cb, vb, add_los, add_cells);
-                }
+                slow = true;
+                const bool mine_in = ((inball >> lane) & 1ull) != 0ull;
+                const double wcn = w_cb + sqrt_u24(dist2(w_xq, xq));
+                const bool cnd = mine_in && wcn < cb;
+                if (__ballot(cnd) != 0ull) test_priced(cnd, wcn, w_vidx, w_xq, xq, cb, vb, add_los, add_cells);
             }
-            const bool acc = pre_ok && same == 0ull && rj != n;  // rrt.py:425
-            RSTAMP(0);
+            const bool acc = pre_ok && !dup && rj != n;  // rrt.py:425
             st_j += (unsigned long long)rj;
-            st_cnn += (unsigned long long)cells_nn;
+            st_cnn += (unsigned long long)rl(rec, PW_CELLSNN);
             if (logs && lane == 0) {
-                bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)nn_idx;
+                bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)rl(rec, PW_NNIDX);
                 bv.accept_log[(size_t)q * bv.n_cap + h] = (uint8_t)acc;
                 bv.cbest_log[(size_t)q * bv.n_cap + h] = __longlong_as_double(0x7ff8000000000000ll);
                 bv.j_log[(size_t)q * bv.n_cap + h] = rj;
             }
-            if (acc) {  // rrt.py:524-529
+            const unsigned long long hbit = 1ull << (h & 63);
+            if (acc) {
                 if (star) {
-                    st_near += (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rec, 6) + (unsigned long long)__builtin_popcountll(inball);
-                    st_los += (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)rec, 10) + add_los);
-                    st_ccand += (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)rec, 11) + add_cells);
+                    st_near += (unsigned long long)rl(rec, PW_HITS) + (unsigned long long)__builtin_popcountll(inball);
+                    st_los += (unsigned long long)(rl(rec, PW_NLOS) + add_los);
+                    st_ccand += (unsigned long long)(rl(rec, PW_CCAND) + add_cells);
                 }
-                const uint32_t pos = ccnt + (uint32_t)__builtin_popcountll(__ballot(pend_cell == (uint32_t)c));
-                if (lane == npend) pend_cell = (uint32_t)c;
-                RSTAMP(1);
-                if (lane == 0) {
-                    nodes_g[rj] = xq;
-                    vcost[rj] = cb;
-                    parent[rj] = (int32_t)vb;
-                    const uint32_t cellb = (uint32_t)ux(xq) * (uint32_t)H + (uint32_t)uy(xq);
-                    atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
-                    const unsigned long long cbits = (unsigned long long)__double_as_longlong(cb);
-                    cellrec[(size_t)c * (size_t)ccap + pos] = u32x4{xq, (uint32_t)rj, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+                const int c = cell_of(xq);
+                const uint32_t pos = rl(rec, PW_CCNT) + (uint32_t)__builtin_popcountll(rl64(rec, PW_CELLMASK) & insbits);
+                if (lane == npend) {  // stored with the batch
+                    p_xq = xq;
+                    p_cb = cb;
+                    p_vb = vb;
+                    p_rj = (uint32_t)rj;
+                    p_rec = (uint32_t)c * (uint32_t)ccap + pos;
+                    p_cell = (uint32_t)c;
                 }
+                if (lane == (h & 63)) {
+                    w_xq = xq;
+                    w_vidx = (uint32_t)rj;
+                    w_cb = cb;
+                }
+                insbits |= hbit;
+                npend += 1;
+                rj += 1;
+            } else {
+                insbits &= ~hbit;
             }
-            // the window: this sample in its lane
-            if (lane == (h & 63)) {
-                w_ins = acc ? 1u : 0u;
-                w_xq = xq;
-                w_vidx = (uint32_t)rj;
-                w_cb = cb;
-            }
-            npend += acc ? 1 : 0;
-            rj += acc ? 1 : 0;
             rh = h + 1;
 #ifdef RRT_STAMPS
             rcyc[6] += 1;
+            if (slow) RSTAMP(2);
+            else RSTAMP(1);
+#else
+            (void)slow;
 #endif
-            if (npend == 16 || rh - pub_h >= 16) {
-                RSTAMP(5);
+            if (npend == 16 || rh - pub_h >= 16 || rh >= n) {
                 publish();
                 RSTAMP(4);
+                if (rh >= n) return -1;
             }
-            if (rh >= n) {
-                RSTAMP(5);
-                publish();
-                RSTAMP(4);
-                return -1;
-            }
-            RSTAMP(2);
             rec = nxt;
+            nxt = nx2;
+#ifdef RRT_STAMPS
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             RSTAMP(5);
+#endif
         }
     };
     if (retirer) __builtin_amdgcn_s_setprio(3);
@@ -394,7 +426,15 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     // The retiring wave has its SIMD to itself: the other waves of the workgroup that landed there only join the barriers.  (The
     // retirement is a chain of ~100 dependent instructions per sample; next to three streaming waves it got one issue slot in
     // four, wave priority or not, and the twelve other waves waited for it.)
-    const bool idle = !retirer && L.simd_of[wave] == L.simd_of[RW];
+#ifndef RRT_PIPE_MATES
+#define RRT_PIPE_MATES 0  // resolving waves that share the retiring wave's SIMD (0..3)
+#endif
+    bool idle = false;
+    if (!retirer && L.simd_of[wave] == L.simd_of[RW]) {
+        int before = 0;  // waves of that SIMD with a lower number
+        for (int w = 0; w < wave; ++w) before += (L.simd_of[w] == L.simd_of[RW]) ? 1 : 0;
+        idle = before >= RRT_PIPE_MATES;
+    }
 #else
     const bool idle = false;
 #endif
@@ -434,9 +474,23 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
         }
         // =============================== resolve sample s against a snapshot ===============================
         {
-            const unsigned long long snap = __hip_atomic_load(&L.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t snap_i = (uint32_t)(snap >> 32), jsnap = (uint32_t)snap;
             const uint32_t xq = samples[s];
+            // the sample before this one whose number is this lane's modulo 64 (the retiring wave keeps the samples in flight by that bit)
+            const int m_l = s - 1 - ((s - 1 - lane) & 63);
+            const uint32_t xm = samples[m_l < 0 ? 0 : m_l];
+            const int own_cell = cell_of(xq);
+            // the snapshot: state and the fill count of the sample's own cell, both as of the same publication
+            unsigned long long snap;
+            uint32_t ccnt_snap;
+            for (;;) {
+                const uint32_t q1 = __hip_atomic_load(&L.pubseq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                snap = __hip_atomic_load(&L.state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ccnt_snap = __hip_atomic_load(&cellcnt[own_cell], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t q2 = __hip_atomic_load(&L.pubseq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((q1 & 1u) == 0u && q1 == q2) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const uint32_t snap_i = (uint32_t)(snap >> 32), jsnap = (uint32_t)snap;
             const uint32_t cell = (uint32_t)ux(xq) * (uint32_t)H + (uint32_t)uy(xq);
             const uint32_t bm_word = __hip_atomic_load(bitmap + (cell >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (set by an L2 atomic: read it there)
             // ---- pass 1 of the record stream: nearest record of the box, |within|, per lane the entry with the smallest bound ----
@@ -564,26 +618,24 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                 }
             }
             DSTAMP(2);
-            if (lane == 0) {
-                PpRec *slot = &L.ring[s & (PP_RING - 1)];
-                PpRec r;
-                r.xq = xq;
-                r.pad0 = 0u;
-                r.nn_idx = nn_idx;
-                r.nn_d2 = nn_d2;
-                r.flags = (nocoll ? 1u : 0u) | (dup ? 2u : 0u);
-                r.cells_nn = (uint32_t)cells;
-                r.hits = nhits;
-                r.vb = vb == NONE ? nn_idx : vb;
-                r.cb = cb;
-                r.n_los = nlos;
-                r.cells_cand = ccells;
-                r.pad1 = 0u;
-                r.snap_i = snap_i;
-                r.ready = 0u;
-                r.vidx = NONE;
-                *slot = r;
-                __hip_atomic_store(&slot->ready, (uint32_t)s + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            {
+                // against the samples in flight since the snapshot (bit m & 63 for sample m in [snap_i, s)): rrt.py:150-155 (a nearer
+                // vertex), :425 (the same grid cell), :176-181 (inside the ball), and the record cell for the insert position
+                const bool fl = m_l >= (int)snap_i;
+                const uint32_t dm = dist2(xm, xq);
+                const unsigned long long nnmask = __ballot(fl && dm < nn_d2), dupmask = __ballot(fl && xm == xq),
+                                         rmask = __ballot(fl && star && dm < r2), cellmask = __ballot(fl && cell_of(xm) == own_cell);
+                if (lane == 0) {
+                    RRT_LDS u32x4 *slot = (RRT_LDS u32x4 *)&L.ring[s & (PP_RING - 1)];
+                    const unsigned long long cbits = (unsigned long long)__double_as_longlong(cb);
+                    slot[0] = u32x4{xq, nn_idx, nn_d2, (nocoll ? 1u : 0u) | (dup ? 2u : 0u)};
+                    slot[1] = u32x4{(uint32_t)cells, nhits, vb == NONE ? nn_idx : vb, nlos};
+                    slot[2] = u32x4{(uint32_t)cbits, (uint32_t)(cbits >> 32), ccells, snap_i};
+                    slot[4] = u32x4{(uint32_t)nnmask, (uint32_t)(nnmask >> 32), (uint32_t)dupmask, (uint32_t)(dupmask >> 32)};
+                    slot[5] = u32x4{(uint32_t)rmask, (uint32_t)(rmask >> 32), (uint32_t)cellmask, (uint32_t)(cellmask >> 32)};
+                    slot[3] = u32x4{0u, ccnt_snap, 0u, 0u};
+                    __hip_atomic_store(&L.ring[s & (PP_RING - 1)].ready, (uint32_t)s + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         DSTAMP(5);  // deposit
@@ -592,10 +644,7 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
         __builtin_amdgcn_s_setprio(0);
 #ifdef RRT_STAMPS
         if (lane == 0) {
-            L.dbg[1] = rcyc[0];  // (diagnostic: the three parts of a head instead of the younger-vertex counts)
-            L.dbg[2] = rcyc[1];
-            for (int k = 3; k < 8; ++k) L.dbg[k] = rcyc[k];
-            L.dbg[3] = rcyc[3] | (rcyc[2] << 40);
+            for (int k = 1; k < 8; ++k) L.dbg[k] = rcyc[k];
         }
 #endif
         if (lane == 0) {

@@ -40,7 +40,7 @@ tot = sum(cyc[:6]) or 1
 for nm, c in zip(names, cyc[:6]): print("  %-34s %12d  %5.1f%%  %8.1f cyc/sample of wave 0" % (nm, c, 100 * c / tot, c * 15 / n))
 print("near %.1f  los_cand %.2f per sample" % (r.c.sum_near / n, r.c.n_los_cand / n))
 print("samples resolved again: %d (%.2f %%)" % (cyc[6], 100.0 * cyc[6] / n))
-wait_head, stores = cyc[9] & ((1 << 40) - 1), cyc[9] >> 40
-tot_r = (wait_head + cyc[10] + cyc[11] + cyc[7] + cyc[8] + stores) or 1
-print("the retiring wave: waiting for the head %.1f %%, publishing %.1f %% (%d publications, %.0f cycles each); %d heads: checks %.0f, position %.0f, stores + window %.0f, next record %.0f cycles each" % (
-    100.0 * wait_head / tot_r, 100.0 * cyc[10] / tot_r, cyc[13], cyc[10] / max(cyc[13], 1), cyc[12], cyc[7] / max(cyc[12], 1), cyc[8] / max(cyc[12], 1), stores / max(cyc[12], 1), cyc[11] / max(cyc[12], 1)))
+tot_r = sum(cyc[7:12]) or 1
+print("the retiring wave: waiting for the head %.1f %%, publishing %.1f %% (%d publications, %.0f cycles each), heads %.1f %% (%d, fast + slow path %.0f cycles each), next record %.1f %% (%.0f cycles each)" % (
+    100.0 * cyc[9] / tot_r, 100.0 * cyc[10] / tot_r, cyc[13], cyc[10] / max(cyc[13], 1), 100.0 * (cyc[7] + cyc[8]) / tot_r, cyc[12], (cyc[7] + cyc[8]) / max(cyc[12], 1),
+    100.0 * cyc[11] / tot_r, cyc[11] / max(cyc[12], 1)))
