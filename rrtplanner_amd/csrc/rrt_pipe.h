@@ -29,6 +29,10 @@
 
 #include "rrt_block.h"
 
+#ifndef RRT_PIPE_STREAM_DEPTH
+#define RRT_PIPE_STREAM_DEPTH 3  // steps of a record stream in flight (measured 1..4: profiles/r03_experiments.md)
+#endif
+
 namespace rrtdev {
 
 constexpr int PP_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
@@ -205,14 +209,20 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                 }
                 return cellrec[idx < total ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
             };
-            // two steps in flight: the next step's records are requested before this step's are looked at
-            u32x4 rc = {0u, 0u, 0u, 0u};
-            if (total > 0u) rc = fetch(0u);
+            // RRT_PIPE_STREAM_DEPTH steps in flight: the records of the next steps are requested before this step's are looked at
+            constexpr int SD = RRT_PIPE_STREAM_DEPTH;
+            u32x4 rq[SD];
+#pragma unroll
+            for (int k = 0; k < SD; ++k) rq[k] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k + 1 < SD; ++k)
+                if ((uint32_t)k * 64u < total) rq[k] = fetch((uint32_t)k * 64u);
             for (uint32_t base = 0; base < total; base += 64u) {
-                u32x4 nx = {0u, 0u, 0u, 0u};
-                if (base + 64u < total) nx = fetch(base + 64u);
-                f(rc, base + (uint32_t)lane < total && rc.y < jsnap);
-                rc = nx;
+                const uint32_t ahead = base + (uint32_t)(SD - 1) * 64u;
+                if (ahead < total) rq[SD - 1] = fetch(ahead);
+                f(rq[0], base + (uint32_t)lane < total && rq[0].y < jsnap);
+#pragma unroll
+                for (int k = 0; k + 1 < SD; ++k) rq[k] = rq[k + 1];
             }
         }
     };

@@ -38,6 +38,7 @@ print(f"kernel {ms:.2f} ms ({b.kernel_name()}), n={n}, nodes={r.c.j}, iters/s={n
 names = ["first record stream", "one price per lane", "lines of sight (nearest + priced)", "pass 2 (stream, prices, lines)", "waiting (window full)", "deposit"]
 tot = sum(cyc[:6]) or 1
 for nm, c in zip(names, cyc[:6]): print("  %-34s %12d  %5.1f%%  %8.1f cyc/sample of wave 0" % (nm, c, 100 * c / tot, c * 15 / n))
+print("wave 0's stamped cycles / kernel time = %.2f GHz" % (tot / (ms * 1e6)))
 print("near %.1f  los_cand %.2f per sample" % (r.c.sum_near / n, r.c.n_los_cand / n))
 print("samples resolved again: %d (%.2f %%)" % (cyc[6], 100.0 * cyc[6] / n))
 tot_r = sum(cyc[7:12]) or 1
