@@ -41,6 +41,7 @@
 namespace rrtdev {
 
 constexpr int DB_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
+constexpr uint32_t DB_TINY = 64;  // a tree of up to this many vertices is looked at as a whole, one vertex per lane (no cell streams)
 constexpr int DB_WIN = 64;   // samples in flight ahead of retirement
 constexpr unsigned long long DB_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
 constexpr int DB_RING = 128; // ring of deposited / retired samples (>= 2 * DB_WIN: a retiring sample looks back at most DB_WIN - 1,
@@ -166,13 +167,18 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     // cell of a record by bisection over that prefix with ds_bpermute), 64 cells at a time.  f(record, live) once per step.
     // Records of vertices at or above `jsnap` (inserted after the caller's snapshot) are dealt as dead lanes.
     auto stream_box = [&](uint32_t X, int rad, uint32_t jsnap, auto &&f) {
+        // a tree of up to 64 vertices: all of them in one step, from the vertex arrays instead of the cells' (the same answers; a
+        // start pose that nothing can be connected to, and the first samples of every run, would otherwise walk ever larger boxes)
+        const bool tiny = jsnap <= DB_TINY;
         const int x = ux(X), y = uy(X);
         const int cx0 = (x - rad < 0 ? 0 : x - rad) >> cshift, cx1 = (x + rad > W - 1 ? W - 1 : x + rad) >> cshift;
         const int cy0 = (y - rad < 0 ? 0 : y - rad) >> cshift, cy1 = (y + rad > H - 1 ? H - 1 : y + rad) >> cshift;
-        const int ny = cy1 - cy0 + 1, ncr = (cx1 - cx0 + 1) * ny;
+        const int ny = cy1 - cy0 + 1, ncr = tiny ? 1 : (cx1 - cx0 + 1) * ny;
         for (int cbase = 0; cbase < ncr; cbase += 64) {
             uint32_t tcnt = 0, toff = 0;
-            if (cbase + lane < ncr) {
+            if (tiny) {
+                tcnt = lane == 0 ? jsnap : 0u;  // (one "cell": the vertex arrays)
+            } else if (cbase + lane < ncr) {
                 const int ci = cbase + lane, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
                 tcnt = cellcnt[cell];
                 toff = (uint32_t)cell * (uint32_t)ccap;
@@ -197,6 +203,11 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 }
                 const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
                 const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
+                if (tiny) {
+                    const uint32_t k = idx < total ? idx : 0u;
+                    const unsigned long long cbits = (unsigned long long)__double_as_longlong(vcost[k]);
+                    return u32x4{nodes_g[k], k, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+                }
                 return cellrec[idx < total ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
             };
             // RRT_DUB_STREAM_DEPTH steps in flight: the records of the next steps are requested before this step's are looked at
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             wave_min_key_idx(nn_d2, nn_idx);
             int radn = rad0;
             // nothing in the box, or something that a vertex outside the box could beat: double the box (nearest only)
-            while ((nn_d2 == NONE || nn_d2 > (uint32_t)radn * (uint32_t)radn) && radn < (W > H ? W : H)) {
+            while (jsnap > DB_TINY && (nn_d2 == NONE || nn_d2 > (uint32_t)radn * (uint32_t)radn) && radn < (W > H ? W : H)) {
                 radn = 2 * radn + 1;
                 ld2 = NONE;
                 lidx = NONE;

@@ -36,6 +36,7 @@
 namespace rrtdev {
 
 constexpr int PP_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
+constexpr uint32_t PP_TINY = 64;  // a tree of up to this many vertices is looked at as a whole, one vertex per lane (no cell streams)
 constexpr int PP_WIN = 64;   // samples in flight ahead of retirement
 constexpr unsigned long long PP_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
 constexpr int PP_RING = 64;  // ring of deposited samples (>= PP_WIN: the slot of sample s is written again for s + PP_RING, which is
@@ -167,13 +168,18 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     // 64 cells at a time.  f(record, live) once per step.
     // Records of vertices at or above `jsnap` (inserted after the caller's snapshot) are dealt as dead lanes.
     auto stream_box = [&](uint32_t X, int rad, uint32_t jsnap, auto &&f) {
+        // a tree of up to 64 vertices: all of them in one step, from the vertex arrays instead of the cells' (the same answers; a
+        // start pose that nothing can be connected to, and the first samples of every run, would otherwise walk ever larger boxes)
+        const bool tiny = jsnap <= PP_TINY;
         const int x = ux(X), y = uy(X);
         const int cx0 = (x - rad < 0 ? 0 : x - rad) >> cshift, cx1 = (x + rad > W - 1 ? W - 1 : x + rad) >> cshift;
         const int cy0 = (y - rad < 0 ? 0 : y - rad) >> cshift, cy1 = (y + rad > H - 1 ? H - 1 : y + rad) >> cshift;
-        const int ny = cy1 - cy0 + 1, ncr = (cx1 - cx0 + 1) * ny;
+        const int ny = cy1 - cy0 + 1, ncr = tiny ? 1 : (cx1 - cx0 + 1) * ny;
         for (int cbase = 0; cbase < ncr; cbase += 64) {
             uint32_t tcnt = 0, toff = 0;
-            if (cbase + lane < ncr) {
+            if (tiny) {
+                tcnt = lane == 0 ? jsnap : 0u;  // (one "cell": the vertex arrays)
+            } else if (cbase + lane < ncr) {
                 const int ci = cbase + lane, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
                 tcnt = cellcnt[cell];
                 toff = (uint32_t)cell * (uint32_t)ccap;
@@ -206,6 +212,11 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                     cur_pre = p;
                     cur_off = o;
                     rest &= rest - 1ull;
+                }
+                if (tiny) {
+                    const uint32_t k = idx < total ? idx : 0u;
+                    const unsigned long long cbits = (unsigned long long)__double_as_longlong(vcost[k]);
+                    return u32x4{nodes_g[k], k, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
                 }
                 return cellrec[idx < total ? coff + (idx - cpre) : 0u];  // {xy, index, vcost}
             };
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
             wave_min_key_idx(nn_d2, nn_idx);
             int radn = rad0;
             // nothing in the box, or something that a vertex outside the box could beat: double the box (nearest only)
-            while ((nn_d2 == NONE || nn_d2 > (uint32_t)radn * (uint32_t)radn) && radn < (W > H ? W : H)) {
+            while (jsnap > PP_TINY && (nn_d2 == NONE || nn_d2 > (uint32_t)radn * (uint32_t)radn) && radn < (W > H ? W : H)) {
                 radn = 2 * radn + 1;
                 ld2 = NONE;
                 lidx = NONE;

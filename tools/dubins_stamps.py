@@ -23,14 +23,17 @@ samples = hostprep.draw_free_samples(rng, np.argwhere(og8 == 0), n)
 heads = rng.integers(0, 64, size=n)
 ctx = _ffi.Context(0); ctx.set_grid(og8)
 serial = len(sys.argv) > 1 and sys.argv[1] == 'serial'
-b = _ffi.Batch(ctx, 1, n, dubins=True, serial=serial)
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # queries running side by side (the stamps are query 0's)
+b = _ffi.Batch(ctx, Q, n, dubins=True, serial=serial)
 q, keep = _ffi.make_query(_ffi.ALG_DUBINS_STAR, n, (int(xs[0]), int(xs[1]), 5), (int(xg[0]), int(xg[1]), 20), samples, r2_rewire=hostprep.radius_threshold(64), headings=heads, rho=8.0, nh=64)
-b.set_query(0, q)
+for k in range(Q):
+    b.set_query(k, q)
 for rep in range(2):
     b.rearm(); b.launch(); b.sync()
 ms = b.elapsed_ms()
 r = b.get_result(0, arrays=False)
 cyc = b.debug_cycles(0)
+print("%d queries side by side" % Q)
 print("kernel %.1f ms, j=%d, %.0f cyc/iter (at 2.4 GHz)" % (ms, r.c.j, ms * 2.4e6 / n))
 print("kernel:", b.kernel_name(), " word evaluations per iteration: %.2f" % (r.c.n_words / n))
 names = (["A scan", "pricing (wave 0's entries)", "wait for the nearest's word + sweep", "acceptance, test rounds", "D insert", "go2goal"] if serial else
