@@ -344,6 +344,43 @@ def test_batch_of_queries_matches_single_queries(gpu_ctx):
     b.close()
 
 
+@pytest.mark.parametrize("pipe1", [True, False])
+def test_more_queries_than_compute_units_one_cu_each(gpu_ctx, pipe1):
+    """300 queries on one CU each (more workgroups than the device has CUs: the last ones start when the first have finished), the
+    barrier-free pipeline and the block kernel; RRTStandard and RRT* mixed, two radii."""
+    og = perlin_occupancygrid(300, 260, seed=5)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    sg = np.random.default_rng(11)
+    Q, n = 300, 400
+    b = _ffi.Batch(gpu_ctx, Q, n, pipe1=pipe1)
+    keep, refs = [], []
+    for q in range(Q):
+        xs, xg = random_connected_pair(og, sg)
+        samples = hostprep.draw_free_samples(np.random.default_rng(1000 + q), free, n)
+        alg, r2 = q % 2, hostprep.radius_threshold(20 if q % 3 else 70)
+        qu, k = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2)
+        keep.append(k)
+        b.set_query(q, qu)
+        refs.append(oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=r2))
+    for rep in range(2):
+        b.launch()
+        b.sync()
+        assert b.kernel_name() == ("rrt_pipe_kernel" if pipe1 else "rrt_expand_block_kernel<1, 16, false, false>")
+        for q in range(Q):
+            res = b.get_result(q)
+            st, ro = refs[q]
+            live = ro.j + (1 if ro.found else 0)
+            assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal, q
+            assert np.array_equal(res.pts[:live], ro.pts[:live]), q
+            assert np.array_equal(res.parent[:live], ro.parent[:live]), q
+            assert np.array_equal(res.vcost[:live], ro.vcost[:live]), q
+            assert res.sum_j == ro.sum_j and res.sum_cells_nn == ro.sum_cells_nn and res.sum_near == ro.sum_near, q
+        b.rearm()
+    b.close()
+
+
 def _bench_config4_queries(og, free, Q, n, first=0, stride=1):
     """bench.py's config-4 queries first, first + stride, ...: start/goal from default_rng(7), planner seed = query index."""
     from rrtplanner_amd.oggen import random_connected_pairs
