@@ -402,10 +402,17 @@ extern "C" int rrt_select_frame(rrt_ctx *ctx, int32_t frame) {
 
 // Near-set record grid of one query: cell edge 2^shift pixels, about half the rewire radius, at most MAX_CELLS
 // cells.  A cell holds at most 4^shift + 1 nodes (one per pixel, plus xstart once more: rrt.py:425) and at most n + 1.
-static void cell_geometry(int W, int H, int64_t r2, int n, int &shift, int &ncx, int &ncy, int &cap) {
+#ifndef RRT_CELL_DIV
+#define RRT_CELL_DIV 2.0  // a cell is at most r_rewire / RRT_CELL_DIV wide (and at least 16) ...
+#endif
+#ifndef RRT_CELL_DIV_PIPE
+#define RRT_CELL_DIV_PIPE 4.0  // ... for a query that the one-CU pipeline runs (rrt_pipe.h: its streams leave out the cells beyond the radius,
+                               // and a step costs them the same however many cells begin in it).  Measured: profiles/r03_experiments.md
+#endif
+static void cell_geometry(int W, int H, int64_t r2, int n, double div, int &shift, int &ncx, int &ncy, int &cap) {
     double r = std::sqrt((double)(r2 < 1 ? 1 : r2));
     shift = 4;
-    while ((1 << (shift + 1)) <= r / 2.0 && shift < 11) ++shift;
+    while ((1 << (shift + 1)) <= r / div && shift < 11) ++shift;
     for (;; ++shift) {
         ncx = (W + (1 << shift) - 1) >> shift;
         ncy = (H + (1 << shift) - 1) >> shift;
@@ -700,7 +707,8 @@ extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu)
         for (int k = 0; k < qu->n; ++k) b->stage8[(size_t)k] = (uint8_t)qu->headings[k];
         HIPCHK(ctx, hipMemcpyAsync(b->d_shead + (size_t)q * b->n_cap, b->stage8.data(), (size_t)qu->n, hipMemcpyHostToDevice, ctx->stream));
     }
-    cell_geometry(W, H, (int64_t)d.r2_rewire, b->n_cap, d.cell_shift, d.ncx, d.ncy, d.cell_cap);
+    const bool pipe1 = b->use_block && b->team == 1 && !(b->flags & RRT_FLAG_NOPIPE1) && qu->alg != RRT_ALG_INFORMED;
+    cell_geometry(W, H, (int64_t)d.r2_rewire, b->n_cap, pipe1 ? RRT_CELL_DIV_PIPE : RRT_CELL_DIV, d.cell_shift, d.ncx, d.ncy, d.cell_cap);
     arm_desc(d);
     HIPCHK(ctx, hipMemcpyAsync(b->d_samples + (size_t)q * b->n_cap, b->stage.data(), (size_t)qu->n * sizeof(uint32_t),
                                hipMemcpyHostToDevice, ctx->stream));

@@ -75,6 +75,7 @@ struct PpLds {
     alignas(16) uint32_t cellcnt[MAX_CELLS];  // live fill counts of the cells; go2goal's two 8 KiB tables afterwards
     alignas(16) u32x4 buf[NWAVE][PP_BUF];     // pass 2: collected entries {xy, index, vcost}
     alignas(16) PpRec ring[PP_RING];
+    uint32_t slots[NWAVE][64];                // the streams' cell starts of a step
     alignas(16) BSlot bslots[2 * NWAVE];
     alignas(8) unsigned long long state;  // samples retired << 32 | vertices: ONE word, so that a snapshot is consistent
     uint32_t next;                        // ticket counter
@@ -121,9 +122,11 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     // radius of the first record stream: the rewire radius, but at least two cells (RRTStandard has no near set, and a tiny
     // radius would leave the nearest-vertex search to the doubling below)
     int rad0 = 0;
+    uint32_t rr0 = 0;  // its square: the stream deals every vertex nearer than that
     {
         const uint32_t two = (uint32_t)((2 << cshift) * (2 << cshift));
         const uint32_t rr = (star && r2 > two) ? r2 : two;
+        rr0 = rr;
         rad0 = (rr >= (1u << 23)) ? 4096 : (int)sqrtf((float)(rr - 1));
         while (rad0 > 0 && (uint32_t)(rad0 * rad0) > rr - 1) --rad0;
         while ((uint32_t)((rad0 + 1) * (rad0 + 1)) <= rr - 1) ++rad0;
@@ -167,7 +170,10 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     // record 64 * step + l of the concatenation of the cells' arrays (exclusive prefix sum of the fill counts over the lanes),
     // 64 cells at a time.  f(record, live) once per step.
     // Records of vertices at or above `jsnap` (inserted after the caller's snapshot) are dealt as dead lanes.
-    auto stream_box = [&](uint32_t X, int rad, uint32_t jsnap, auto &&f) {
+    // `keep_d2`: every vertex at a squared distance up to this must be dealt (cells farther away than that are left out: the corners
+    // of the box, a third of its records where the cells are small against the radius).
+    volatile RRT_LDS uint32_t *slots = (volatile RRT_LDS uint32_t *)L.slots[wave];  // (lanes talk to each other through it: every access as written)
+    auto stream_box = [&](uint32_t X, int rad, uint32_t keep_d2, uint32_t jsnap, auto &&f) {
         // a tree of up to 64 vertices: all of them in one step, from the vertex arrays instead of the cells' (the same answers; a
         // start pose that nothing can be connected to, and the first samples of every run, would otherwise walk ever larger boxes)
         const bool tiny = jsnap <= PP_TINY;
@@ -180,8 +186,12 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
             if (tiny) {
                 tcnt = lane == 0 ? jsnap : 0u;  // (one "cell": the vertex arrays)
             } else if (cbase + lane < ncr) {
-                const int ci = cbase + lane, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
-                tcnt = cellcnt[cell];
+                const int ci = cbase + lane, ccx = cx0 + ci / ny, ccy = cy0 + ci % ny, cell = ccx * ncy + ccy;
+                // squared distance of the sample to the cell's rectangle
+                const int xl = ccx << cshift, xh = xl + (1 << cshift) - 1, yl = ccy << cshift, yh = yl + (1 << cshift) - 1;
+                const int ddx = x < xl ? xl - x : (x > xh ? x - xh : 0), ddy = y < yl ? yl - y : (y > yh ? y - yh : 0);
+                const uint32_t md2 = (uint32_t)(ddx * ddx + ddy * ddy);
+                tcnt = md2 <= keep_d2 ? cellcnt[cell] : 0u;
                 toff = (uint32_t)cell * (uint32_t)ccap;
             }
             uint32_t incl = tcnt;
@@ -193,26 +203,29 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t pre = incl - tcnt;
-            // Which cell a record belongs to, without a search: the non-empty cells are started one after the other as the
-            // stream reaches their first record (lane-uniform walk over the set bits of `rest`; the prefix and the offset of a
-            // cell come by v_readlane), so a step costs a few scalar instructions per cell that begins in it and no LDS traffic.
-            unsigned long long rest = __ballot(tcnt != 0u);
-            uint32_t cur_pre = 0, cur_off = 0;  // the cell that holds the record before this step's first
+            // Which cell a record belongs to, without a search and without a loop over the cells: every non-empty cell whose first
+            // record falls into this step writes its number into that record's slot (64 words of LDS per wave), the lanes read
+            // their slots and a running maximum over the lanes (DPP) carries the number to the records behind it; the lanes in
+            // front of the step's first cell start belong to the cell the last step ended in.
+            int cur_c = 0;
             auto fetch = [&](uint32_t base) -> u32x4 {
                 const uint32_t idx = base + (uint32_t)lane;
-                uint32_t cpre = cur_pre, coff = cur_off;
-                while (rest != 0ull) {
-                    const int cl = (int)__builtin_ctzll(rest);
-                    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pre, cl);
-                    if (p >= base + 64u) break;
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)toff, cl);
-                    const bool in = idx >= p;
-                    cpre = in ? p : cpre;
-                    coff = in ? o : coff;
-                    cur_pre = p;
-                    cur_off = o;
-                    rest &= rest - 1ull;
-                }
+                slots[lane] = NONE;
+                const uint32_t rel = pre - base;
+                __builtin_amdgcn_wave_barrier();
+                if (tcnt != 0u && rel < 64u) slots[rel] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                int cv = (int)slots[lane];  // (NONE = -1)
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x111, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x112, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x114, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x118, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x142, 0xa, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x143, 0xc, 0xf, false));
+                cv = cv < 0 ? cur_c : cv;
+                cur_c = __builtin_amdgcn_readlane(cv, 63);
+                const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute(cv << 2, (int)pre);
+                const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute(cv << 2, (int)toff);
                 if (tiny) {
                     const uint32_t k = idx < total ? idx : 0u;
                     const unsigned long long cbits = (unsigned long long)__double_as_longlong(vcost[k]);
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
             uint32_t ld2 = NONE, lidx = NONE, lxy = 0, lvl = 0, lvh = 0;  // this lane's nearest record
             float m1f = FINF, m2f = FINF;                                 // smallest / second smallest bound among this lane's hits
             uint32_t m1idx = NONE, m1xy = 0, m1vl = 0, m1vh = 0;
-            stream_box(xq, rad0, jsnap, [&](const u32x4 rc, bool live) {
+            stream_box(xq, rad0, rr0 - 1u, jsnap, [&](const u32x4 rc, bool live) {
                 const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                 const bool nearer = d2 < ld2 || (d2 == ld2 && live && rc.y < lidx);
                 ld2 = nearer ? d2 : ld2;
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                 radn = 2 * radn + 1;
                 ld2 = NONE;
                 lidx = NONE;
-                stream_box(xq, radn, jsnap, [&](const u32x4 rc, bool live) {
+                stream_box(xq, radn, (uint32_t)radn * (uint32_t)radn, jsnap, [&](const u32x4 rc, bool live) {
                     const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                     const bool nearer = d2 < ld2 || (d2 == ld2 && live && rc.y < lidx);
                     ld2 = nearer ? d2 : ld2;
@@ -624,7 +637,7 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                         if (tail) buf[lane] = mv;
                         nbuf = nbuf > 64u ? nbuf - 64u : 0u;
                     };
-                    stream_box(xq, rad0, jsnap, [&](const u32x4 rc, bool live) {
+                    stream_box(xq, rad0, rr0 - 1u, jsnap, [&](const u32x4 rc, bool live) {
                         const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                         const double V = __longlong_as_double((long long)(((unsigned long long)rc.w << 32) | rc.z));
                         const bool take = d2 < r2 && rc.y != nn_idx && rc.y != skip && (double)pp_lower_bound(V, d2) < cb;
