@@ -37,6 +37,7 @@ namespace rrtdev {
 
 constexpr int PP_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
 constexpr uint32_t PP_TINY = 64;  // a tree of up to this many vertices is looked at as a whole, one vertex per lane (no cell streams)
+constexpr int PP_KB = 16;   // most heads retired in one pass
 constexpr int PP_WIN = 64;   // samples in flight ahead of retirement
 constexpr unsigned long long PP_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
 constexpr int PP_RING = 64;  // ring of deposited samples (>= PP_WIN: the slot of sample s is written again for s + PP_RING, which is
@@ -76,6 +77,10 @@ struct PpLds {
     alignas(16) u32x4 buf[NWAVE][PP_BUF];     // pass 2: collected entries {xy, index, vcost}
     alignas(16) PpRec ring[PP_RING];
     uint32_t slots[NWAVE][64];                // the streams' cell starts of a step
+    alignas(16) u32x4 win[64];                // position m & 63: the vertex sample m became {xy, index, cost} (the retiring wave's)
+    alignas(16) u32x4 winb[PP_KB];            // the same for the heads of the pass being decided, by lane (their positions in `win` still
+                                              // hold the samples 64 earlier, which a lower head of the pass may have to look at)
+    uint32_t pendcell[64];                    // record cells of the insertions whose fill counts are not published yet
     alignas(16) BSlot bslots[2 * NWAVE];
     alignas(8) unsigned long long state;  // samples retired << 32 | vertices: ONE word, so that a snapshot is consistent
     uint32_t next;                        // ticket counter
@@ -279,24 +284,25 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     };
 
     // ---- retirement: ONE wave (the last) retires the samples in order and does nothing else: it is the one serial chain of the
-    //      kernel.  Per sample a handful of scalar operations: the record's masks against the bits of the samples inserted last
-    //      (bit m & 63 <-> sample m) say whether a younger vertex is nearer than the snapshot's nearest (resolve again), sits on
-    //      the same grid cell (reject), or lies in the ball (one more candidate parent: those are priced, lane m & 63 holds the
-    //      sample's position, vertex and cost).  Insertions wait in lanes and are stored 16 at a time; their stores are acknowledged
-    //      once per batch (s_waitcnt vmcnt(0)), then the fill counts and the state name them.
+    //      kernel.  Up to PP_KB heads that are ready are decided in ONE pass, lane k the head rh + k: a record's masks against the
+    //      bits of the samples inserted last (bit m & 63 <-> sample m; for the lower heads of the same pass their acceptance, found
+    //      by a fixed-point iteration over ballots) say whether a younger vertex is nearer than the snapshot's nearest (resolve
+    //      again: the pass ends in front of that head), sits on the same grid cell (reject), or lies in the ball (one more
+    //      candidate parent: priced from L.win, position m & 63 holds the vertex of sample m; a candidate that would win -- one
+    //      sample in a thousand -- ends the pass in front of its head, which is then retired on its own with the line-of-sight
+    //      tests).  The accepted heads are stored lane-parallel; their stores are acknowledged once per batch (s_waitcnt vmcnt(0)),
+    //      then the fill counts and the state name them.
     //      Returns the number of a head that has to be resolved again against the exact tree (the retiring wave does that itself),
     //      -1 when everything is retired (or the run failed). ----
     constexpr int RW = NWAVE - 1;
     const bool retirer = wave == RW;
     int rh = i, rj = j, pub_h = i;          // next sample to retire, vertices (the unpublished ones included), samples published
     unsigned long long insbits = 0ull;      // bit m & 63: sample m (one of the last 64) was inserted
-    uint32_t w_xq = 0u, w_vidx = NONE;      // lane m & 63: where, as which vertex, at what cost
-    double w_cb = 0.0;
-    uint32_t p_xq = 0u, p_vb = 0u, p_rj = 0u, p_rec = 0u, p_cell = 0u;  // insertions not stored yet: lane k holds the k-th
-    double p_cb = 0.0;
-    int npend = 0;
-    unsigned long long st_j = 0, st_cnn = 0, st_near = 0, st_ccand = 0, st_los = 0;  // statistics (uniform)
+    int npend = 0;                          // insertions stored but not published: their record cells wait in L.pendcell
+    unsigned long long a_j = 0, a_cnn = 0, a_near = 0, a_ccand = 0, a_los = 0;  // statistics, summed per lane and folded at the end
     const RRT_LDS uint32_t *ringw = (const RRT_LDS uint32_t *)&L.ring[0];
+    volatile RRT_LDS uint32_t *pendcell = (volatile RRT_LDS uint32_t *)L.pendcell;
+    RRT_LDS u32x4 *win = (RRT_LDS u32x4 *)L.win;
 #ifdef RRT_STAMPS
     unsigned long long rt_mark = 0, rcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (uniform: scalar registers)
 #define RSTAMP(k)                                                  \
@@ -310,22 +316,14 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     do {          \
     } while (0)
 #endif
+    auto rotl = [](unsigned long long x, int b) -> unsigned long long { return b ? (x << b) | (x >> (64 - b)) : x; };
     auto publish = [&]() {
         if (rh == pub_h) return;
         if (lane == 0) __hip_atomic_store(&L.pubseq, 2u * (uint32_t)pub_h + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (npend > 0) {
-            if (lane < npend) {  // rrt.py:524-529
-                nodes_g[p_rj] = p_xq;
-                vcost[p_rj] = p_cb;
-                parent[p_rj] = (int32_t)p_vb;
-                const uint32_t cellb = (uint32_t)ux(p_xq) * (uint32_t)H + (uint32_t)uy(p_xq);
-                atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
-                const unsigned long long cbits = (unsigned long long)__double_as_longlong(p_cb);
-                cellrec[p_rec] = u32x4{p_xq, p_rj, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
-            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane < npend) __hip_atomic_fetch_add(&cellcnt[p_cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane < npend) __hip_atomic_fetch_add(&cellcnt[pendcell[lane]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (lane == 0) {
             __hip_atomic_store(&L.state, ((unsigned long long)(uint32_t)rh << 32) | (uint32_t)rj, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -337,29 +335,95 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
         rcyc[7] += 1;
 #endif
     };
-    auto load_rec = [&](int h) -> uint32_t { return ringw[(uint32_t)(h & (PP_RING - 1)) * 32u + (uint32_t)(lane & 31)]; };
+    // rrt.py:524-529 for the lanes with `acc` (their sample s, vertex number v, position `pos` in record cell c); `rank`: how many
+    // lanes below this one insert too
+    auto store_vertex = [&](bool acc, int s, uint32_t xq, double cb, uint32_t vb, uint32_t v, int c, uint32_t pos, int rank) {
+        if (acc) {
+            nodes_g[v] = xq;
+            vcost[v] = cb;
+            parent[v] = (int32_t)vb;
+            const uint32_t cellb = (uint32_t)ux(xq) * (uint32_t)H + (uint32_t)uy(xq);
+            atomicOr(&bitmap[cellb >> 5], 1u << (cellb & 31));  // rrt.py:426
+            const unsigned long long cbits = (unsigned long long)__double_as_longlong(cb);
+            const u32x4 rc = u32x4{xq, v, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+            cellrec[(size_t)c * (size_t)ccap + pos] = rc;
+            win[s & 63] = rc;  // (what younger samples in flight are checked against)
+            pendcell[npend + rank] = (uint32_t)c;
+        }
+    };
     auto rl = [&](uint32_t v, int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); };
     auto rl64 = [&](uint32_t v, int k) -> unsigned long long { return ((unsigned long long)rl(v, k + 1) << 32) | rl(v, k); };
+    // one head on its own (ready): the capacity's end, and a head with a younger vertex that is cheaper than its parent
+    auto retire_one = [&]() -> int {
+        const int h = rh;
+        const uint32_t rec = ringw[(uint32_t)(h & (PP_RING - 1)) * 32u + (uint32_t)(lane & 31)];
+        const uint32_t xq = rl(rec, PW_XQ), flags = rl(rec, PW_FLAGS);
+        if ((rl64(rec, PW_NNMASK) & insbits) != 0ull) return h;  // a younger vertex is nearer: resolve again
+        const bool pre_ok = (flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before its snapshot
+        const bool dup = (rl64(rec, PW_DUPMASK) & insbits) != 0ull;
+        const unsigned long long inball = star ? (rl64(rec, PW_RMASK) & insbits) : 0ull;
+        uint32_t vb = rl(rec, PW_VB);
+        double cb = __longlong_as_double((long long)rl64(rec, PW_CB));
+        uint32_t add_los = 0, add_cells = 0;
+        if (pre_ok && !dup && inball != 0ull) {
+            // A younger vertex inside the ball is one more candidate parent (rrt.py:515-521 walks it too): the ones below the chosen
+            // cost are tested, cheapest first (a younger vertex loses every tie against the snapshot's choice: higher index)
+            const bool mine_in = ((inball >> lane) & 1ull) != 0ull;
+            const u32x4 e = win[lane];
+            const double wcn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z)) + sqrt_u24(dist2(e.x, xq));
+            const bool cnd = mine_in && wcn < cb;
+            if (__ballot(cnd) != 0ull) test_priced(cnd, wcn, e.y, e.x, xq, cb, vb, add_los, add_cells);
+        }
+        const bool acc = pre_ok && !dup && rj != n;  // rrt.py:425
+        if (logs && lane == 0) {
+            bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)rl(rec, PW_NNIDX);
+            bv.accept_log[(size_t)q * bv.n_cap + h] = (uint8_t)acc;
+            bv.cbest_log[(size_t)q * bv.n_cap + h] = __longlong_as_double(0x7ff8000000000000ll);
+            bv.j_log[(size_t)q * bv.n_cap + h] = rj;
+        }
+        const unsigned long long hbit = 1ull << (h & 63);
+        if (lane == 0) {
+            a_j += (unsigned long long)rj;
+            a_cnn += (unsigned long long)rl(rec, PW_CELLSNN);
+            if (acc && star) {
+                a_near += (unsigned long long)rl(rec, PW_HITS) + (unsigned long long)__builtin_popcountll(inball);
+                a_los += (unsigned long long)(rl(rec, PW_NLOS) + add_los);
+                a_ccand += (unsigned long long)(rl(rec, PW_CCAND) + add_cells);
+            }
+        }
+        const int c = cell_of(xq);
+        const uint32_t pos = rl(rec, PW_CCNT) + (uint32_t)__builtin_popcountll(rl64(rec, PW_CELLMASK) & insbits);
+        store_vertex(acc && lane == 0, h, xq, cb, vb, (uint32_t)rj, c, pos, 0);
+        insbits = acc ? (insbits | hbit) : (insbits & ~hbit);
+        npend += acc ? 1 : 0;
+        rj += acc ? 1 : 0;
+        rh = h + 1;
+        return -1;
+    };
     auto retire = [&]() -> int {
 #ifdef RRT_STAMPS
         rt_mark = __builtin_amdgcn_s_memtime();
 #endif
-        if (rh >= n) {
-            publish();
-            return -1;
-        }
-        uint32_t rec = load_rec(rh);
-        uint32_t nxt = rh + 1 < n ? load_rec(rh + 1) : 0u;
         for (;;) {
-            // ---- the head's record (bounded waiting) ----
-            if (rl(rec, PW_READY) != (uint32_t)rh + 1u) {
-                publish();  // nothing to do: what is retired becomes visible
+            if (npend >= 16 || rh - pub_h >= 16 || rh >= n) {
+                publish();
+                RSTAMP(4);
+                if (rh >= n) return -1;
+            }
+            // ---- the heads that are ready: lane k <-> sample rh + k ----
+            const int s = rh + lane;
+            const bool mayb = lane < PP_KB && s < n;
+            const RRT_LDS uint32_t *rw = ringw + (uint32_t)(s & (PP_RING - 1)) * 32u;
+            const uint32_t rdy = mayb ? __hip_atomic_load(rw + PW_READY, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            const unsigned long long rdm = __ballot(mayb && rdy == (uint32_t)s + 1u);
+            const int K = (int)__builtin_ctzll(~rdm);  // (consecutive from the head)
+            if (K == 0) {  // nothing to do: what is retired becomes visible; bounded waiting for the head
+                publish();
                 RSTAMP(4);
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
-                    rec = load_rec(rh);
-                    nxt = rh + 1 < n ? load_rec(rh + 1) : 0u;
-                    if (rl(rec, PW_READY) == (uint32_t)rh + 1u) break;
+                    const uint32_t r0 = __hip_atomic_load(ringw + (uint32_t)(rh & (PP_RING - 1)) * 32u + PW_READY, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (r0 == (uint32_t)rh + 1u) break;
                     if (wall_clock64() - t0 > PP_STALL_TICKS) {  // (never seen; everything retired so far is published above)
                         if (lane == 0) __hip_atomic_store(&L.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         return -1;
@@ -367,92 +431,136 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                     __builtin_amdgcn_s_sleep(1);
                 }
                 RSTAMP(3);
+                continue;
             }
-            const int h = rh;
-            const uint32_t nx2 = h + 2 < n ? load_rec(h + 2) : 0u;  // the records of the next two heads are in flight meanwhile
-            const uint32_t xq = rl(rec, PW_XQ), flags = rl(rec, PW_FLAGS);
-            if ((rl64(rec, PW_NNMASK) & insbits) != 0ull) {  // a younger vertex is nearer (it loses ties: higher index): resolve again
+            if (rj + K >= n) {  // the vertex array is about to be full (rrt.py:425, j != n): one head at a time
+                const int r1 = retire_one();
+                RSTAMP(2);
+                if (r1 >= 0) {
+                    publish();
+                    RSTAMP(4);
+                    return r1;
+                }
+                continue;
+            }
+            // ---- the records, one per lane ----
+            const bool in = lane < K;
+            uint32_t xq = 0, flags = 0, vb = 0, ccnt = 0, hits = 0, nlos = 0, ccand = 0, cnn = 0, nnidx = 0;
+            unsigned long long nnm = 0, dupm = 0, rmk = 0, cmk = 0;
+            double cb = 0.0;
+            if (in) {
+                xq = rw[PW_XQ];
+                flags = rw[PW_FLAGS];
+                vb = rw[PW_VB];
+                ccnt = rw[PW_CCNT];
+                hits = rw[PW_HITS];
+                nlos = rw[PW_NLOS];
+                ccand = rw[PW_CCAND];
+                cnn = rw[PW_CELLSNN];
+                if (logs) nnidx = rw[PW_NNIDX];
+                nnm = ((unsigned long long)rw[PW_NNMASK + 1] << 32) | rw[PW_NNMASK];
+                dupm = ((unsigned long long)rw[PW_DUPMASK + 1] << 32) | rw[PW_DUPMASK];
+                rmk = ((unsigned long long)rw[PW_RMASK + 1] << 32) | rw[PW_RMASK];
+                cmk = ((unsigned long long)rw[PW_CELLMASK + 1] << 32) | rw[PW_CELLMASK];
+                cb = __longlong_as_double((long long)(((unsigned long long)rw[PW_CB + 1] << 32) | rw[PW_CB]));
+            }
+            const int base = rh & 63;
+            const unsigned long long lowk = (1ull << lane) - 1ull;               // the lanes below this one
+            const unsigned long long LP = rotl(lowk, base);                       // ... as sample bits: the lower heads of this pass
+            // the samples before this pass, as this head sees them (the positions of the HIGHER heads of the pass still hold the
+            // samples 64 earlier, which a full window reaches back to)
+            const unsigned long long old = insbits & ~LP;
+            const bool pre_ok = in && (flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before its snapshot
+            // which heads are inserted (rrt.py:425): a head is not if an inserted younger sample sits on its cell -- for the lower
+            // heads of the pass that is what is being decided, so iterate (lane k is final after k rounds; one or two in practice)
+            unsigned long long A_l = __ballot(pre_ok && (dupm & old) == 0ull);
+            for (;;) {
+                const unsigned long long A_p = rotl(A_l, base);
+                const unsigned long long A2 = __ballot(pre_ok && (dupm & (old | (A_p & LP))) == 0ull);
+                if (A2 == A_l) break;
+                A_l = A2;
+            }
+            const unsigned long long young = old | (rotl(A_l, base) & LP);  // per lane: the inserted samples this head has to look at
+            // a younger vertex nearer than the snapshot's nearest (it loses ties: higher index): the pass ends in front of that head
+            const unsigned long long redo_l = __ballot(in && (nnm & young) != 0ull);
+            int Kc = redo_l != 0ull ? (int)__builtin_ctzll(redo_l) : K;
+            bool redo_cut = redo_l != 0ull;
+            const uint32_t vk = (uint32_t)rj + (uint32_t)__builtin_popcountll(A_l & lowk);  // the vertex number of this head (if inserted)
+            bool acc = ((A_l >> lane) & 1ull) != 0ull && lane < Kc;
+            const int c = cell_of(xq);
+            const uint32_t pos = ccnt + (uint32_t)__builtin_popcountll(cmk & young);
+            const unsigned long long accl0 = __ballot(acc);
+            if (acc) {  // (the higher heads of the pass price it as a candidate parent below)
+                const unsigned long long cbits = (unsigned long long)__double_as_longlong(cb);
+                L.winb[lane] = u32x4{xq, vk, (uint32_t)cbits, (uint32_t)(cbits >> 32)};
+            }
+            // younger vertices inside the ball are further candidate parents (rrt.py:515-521 walks them too): one that is cheaper
+            // than the chosen parent needs its line of sight tested -- rare; the pass then ends in front of that head
+            unsigned long long rc = (acc && star) ? (rmk & young) : 0ull;
+            const uint32_t nball = (uint32_t)__builtin_popcountll(rc);
+            unsigned long long hitl = 0ull;
+            while (__ballot(rc != 0ull) != 0ull) {
+                bool hit = false;
+                if (rc != 0ull) {
+                    const int pp = (int)__builtin_ctzll(rc);
+                    rc &= rc - 1ull;
+                    const u32x4 e = ((LP >> pp) & 1ull) != 0ull ? L.winb[(pp - base) & 63] : win[pp];  // a lower head of this pass / an older sample
+                    const double wcn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z)) + sqrt_u24(dist2(e.x, xq));
+                    hit = wcn < cb;
+                }
+                hitl |= __ballot(hit);
+            }
+            bool slow_cut = false;
+            if (hitl != 0ull && (int)__builtin_ctzll(hitl) < Kc) {
+                Kc = (int)__builtin_ctzll(hitl);
+                slow_cut = true;
+                redo_cut = false;
+            }
+            acc = acc && lane < Kc;
+            const unsigned long long accl = accl0 & ((1ull << Kc) - 1ull);
+            const int nacc = __builtin_popcountll(accl);
+            store_vertex(acc, s, xq, cb, vb, vk, c, pos, __builtin_popcountll(accl & lowk));
+            if (lane < Kc) {
+                a_j += (unsigned long long)vk;
+                a_cnn += (unsigned long long)cnn;
+                if (logs) {
+                    bv.nearest_log[(size_t)q * bv.n_cap + s] = (int32_t)nnidx;
+                    bv.accept_log[(size_t)q * bv.n_cap + s] = (uint8_t)acc;
+                    bv.cbest_log[(size_t)q * bv.n_cap + s] = __longlong_as_double(0x7ff8000000000000ll);
+                    bv.j_log[(size_t)q * bv.n_cap + s] = (int32_t)vk;
+                }
+            }
+            if (acc && star) {
+                a_near += (unsigned long long)hits + (unsigned long long)nball;
+                a_los += (unsigned long long)nlos;
+                a_ccand += (unsigned long long)ccand;
+            }
+            insbits = (insbits & ~rotl((1ull << Kc) - 1ull, base)) | rotl(accl, base);
+            npend += nacc;
+            rj += nacc;
+            rh += Kc;
+#ifdef RRT_STAMPS
+            rcyc[6] += (unsigned long long)Kc;
+            rcyc[0] += 1;
+#endif
+            RSTAMP(1);
+            if (redo_cut) {
 #ifdef RRT_STAMPS
                 if (lane == 0) L.dbg[0] += 1;
 #endif
-                RSTAMP(1);
                 publish();  // the exact tree: everything retired is visible to the snapshot it takes
                 RSTAMP(4);
-                return h;
+                return rh;
             }
-            const bool pre_ok = (flags & 3u) == 1u;  // visible from the nearest vertex, cell not sampled before its snapshot
-            const bool dup = (rl64(rec, PW_DUPMASK) & insbits) != 0ull;
-            const unsigned long long inball = rl64(rec, PW_RMASK) & insbits;
-            uint32_t vb = rl(rec, PW_VB);
-            double cb = __longlong_as_double((long long)rl64(rec, PW_CB));
-            uint32_t add_los = 0, add_cells = 0;
-            bool slow = false;
-            if (pre_ok && !dup && inball != 0ull) {
-                // A younger vertex inside the ball is one more candidate parent (rrt.py:515-521 walks it too): the ones below
-                // the chosen cost are tested, cheapest first (a younger vertex loses every tie against the snapshot's choice:
-                // higher index)
-                slow = true;
-                const bool mine_in = ((inball >> lane) & 1ull) != 0ull;
-                const double wcn = w_cb + sqrt_u24(dist2(w_xq, xq));
-                const bool cnd = mine_in && wcn < cb;
-                if (__ballot(cnd) != 0ull) test_priced(cnd, wcn, w_vidx, w_xq, xq, cb, vb, add_los, add_cells);
-            }
-            const bool acc = pre_ok && !dup && rj != n;  // rrt.py:425
-            st_j += (unsigned long long)rj;
-            st_cnn += (unsigned long long)rl(rec, PW_CELLSNN);
-            if (logs && lane == 0) {
-                bv.nearest_log[(size_t)q * bv.n_cap + h] = (int32_t)rl(rec, PW_NNIDX);
-                bv.accept_log[(size_t)q * bv.n_cap + h] = (uint8_t)acc;
-                bv.cbest_log[(size_t)q * bv.n_cap + h] = __longlong_as_double(0x7ff8000000000000ll);
-                bv.j_log[(size_t)q * bv.n_cap + h] = rj;
-            }
-            const unsigned long long hbit = 1ull << (h & 63);
-            if (acc) {
-                if (star) {
-                    st_near += (unsigned long long)rl(rec, PW_HITS) + (unsigned long long)__builtin_popcountll(inball);
-                    st_los += (unsigned long long)(rl(rec, PW_NLOS) + add_los);
-                    st_ccand += (unsigned long long)(rl(rec, PW_CCAND) + add_cells);
+            if (slow_cut) {
+                const int r1 = retire_one();
+                RSTAMP(2);
+                if (r1 >= 0) {
+                    publish();
+                    RSTAMP(4);
+                    return r1;
                 }
-                const int c = cell_of(xq);
-                const uint32_t pos = rl(rec, PW_CCNT) + (uint32_t)__builtin_popcountll(rl64(rec, PW_CELLMASK) & insbits);
-                if (lane == npend) {  // stored with the batch
-                    p_xq = xq;
-                    p_cb = cb;
-                    p_vb = vb;
-                    p_rj = (uint32_t)rj;
-                    p_rec = (uint32_t)c * (uint32_t)ccap + pos;
-                    p_cell = (uint32_t)c;
-                }
-                if (lane == (h & 63)) {
-                    w_xq = xq;
-                    w_vidx = (uint32_t)rj;
-                    w_cb = cb;
-                }
-                insbits |= hbit;
-                npend += 1;
-                rj += 1;
-            } else {
-                insbits &= ~hbit;
             }
-            rh = h + 1;
-#ifdef RRT_STAMPS
-            rcyc[6] += 1;
-            if (slow) RSTAMP(2);
-            else RSTAMP(1);
-#else
-            (void)slow;
-#endif
-            if (npend == 16 || rh - pub_h >= 16 || rh >= n) {
-                publish();
-                RSTAMP(4);
-                if (rh >= n) return -1;
-            }
-            rec = nxt;
-            nxt = nx2;
-#ifdef RRT_STAMPS
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            RSTAMP(5);
-#endif
         }
     };
     if (retirer) __builtin_amdgcn_s_setprio(3);
@@ -677,17 +785,15 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     if (retirer) {
         __builtin_amdgcn_s_setprio(0);
 #ifdef RRT_STAMPS
-        if (lane == 0) {
+        if (lane == 0)
             for (int k = 1; k < 8; ++k) L.dbg[k] = rcyc[k];
-        }
+        if (lane == 0) L.dbg[2] = rcyc[0] | (rcyc[2] << 24);
 #endif
-        if (lane == 0) {
-            L.stat[0] = st_j;
-            L.stat[1] = st_cnn;
-            L.stat[2] = st_near;
-            L.stat[3] = st_ccand;
-            L.stat[4] = st_los;
-        }
+        atomicAdd(&L.stat[0], a_j);
+        atomicAdd(&L.stat[1], a_cnn);
+        atomicAdd(&L.stat[2], a_near);
+        atomicAdd(&L.stat[3], a_ccand);
+        atomicAdd(&L.stat[4], a_los);
     }
     __syncthreads();
     {

@@ -41,7 +41,8 @@ for nm, c in zip(names, cyc[:6]): print("  %-34s %12d  %5.1f%%  %8.1f cyc/sample
 print("wave 0's stamped cycles / kernel time = %.2f GHz" % (tot / (ms * 1e6)))
 print("near %.1f  los_cand %.2f per sample" % (r.c.sum_near / n, r.c.n_los_cand / n))
 print("samples resolved again: %d (%.2f %%)" % (cyc[6], 100.0 * cyc[6] / n))
-tot_r = sum(cyc[7:12]) or 1
-print("the retiring wave: waiting for the head %.1f %%, publishing %.1f %% (%d publications, %.0f cycles each), heads %.1f %% (%d, fast + slow path %.0f cycles each), next record %.1f %% (%.0f cycles each)" % (
-    100.0 * cyc[9] / tot_r, 100.0 * cyc[10] / tot_r, cyc[13], cyc[10] / max(cyc[13], 1), 100.0 * (cyc[7] + cyc[8]) / tot_r, cyc[12], (cyc[7] + cyc[8]) / max(cyc[12], 1),
-    100.0 * cyc[11] / tot_r, cyc[11] / max(cyc[12], 1)))
+passes, one_cyc = cyc[8] & ((1 << 24) - 1), cyc[8] >> 24
+tot_r = (cyc[7] + one_cyc + cyc[9] + cyc[10]) or 1
+print("the retiring wave: waiting for the head %.1f %%, publishing %.1f %% (%d publications, %.0f cycles each), passes %.1f %% (%d passes, %.2f heads and %.0f cycles each), heads on their own %.1f %%" % (
+    100.0 * cyc[9] / tot_r, 100.0 * cyc[10] / tot_r, cyc[13], cyc[10] / max(cyc[13], 1), 100.0 * cyc[7] / tot_r, passes, cyc[12] / max(passes, 1), cyc[7] / max(passes, 1),
+    100.0 * one_cyc / tot_r))
