@@ -7,7 +7,7 @@
 // retires them in order.  Results equal the sequential loop (and the block kernel's, rrt_block.h, which keeps the Informed planner
 // and the teams).
 //
-//   resolve   (12 waves) take the next sample off a ticket counter, at most PP_WIN ahead of retirement.  One stream of the records
+//   resolve   (15 waves) take the next sample off a ticket counter, at most PP_WIN ahead of retirement.  One stream of the records
 //             of the cells the radius ball touches: nearest vertex (near()[0], rrt.py:150-155), |within| (:176-181), and per lane
 //             the entry with the smallest single-precision lower bound of cost = vcost + sqrt(d2); the 64 lane minima are priced
 //             exactly (f64, sqrt_u24) and tried in (cost, index) order below the cost through the nearest vertex until one has a
@@ -16,15 +16,15 @@
 //             in LDS together with four 64-bit masks over the samples still in flight at the snapshot (the sample stream is an
 //             input, rrt.py:240): nearer than the nearest vertex found / on the same grid cell / inside the ball / in the same
 //             record cell.
-//   retire    (1 wave, alone on its SIMD: the three other waves that landed there only join the barriers) the one serial chain of
-//             the kernel, a few scalar operations per sample: the record's masks against the bits of the samples inserted last
-//             decide "resolve again" (a younger vertex is nearer: the retiring wave does it itself, against the exact tree),
-//             "reject" (same grid cell, rrt.py:425), and which younger vertices are further candidate parents (priced and tested
-//             right there).  Insertions are stored 16 at a time; fill counts and state are published behind their acknowledgement.
+//   retire    (1 wave) the one serial chain of the kernel: up to PP_KB ready samples per pass, one lane each; the records' masks
+//             against the bits of the samples inserted last decide "resolve again" (a younger vertex is nearer: the retiring wave
+//             does it itself, against the exact tree), "reject" (same grid cell, rrt.py:425), and which younger vertices are further
+//             candidate parents (priced right there; one that wins sends its sample through the one-at-a-time path with the
+//             line-of-sight tests).  Insertions are stored lane-parallel; fill counts and state are published behind their
+//             acknowledgement.
 //
-// Measured (profiles/r03_experiments.md): the retirement decides the run time as long as it costs more than a twelfth of a
-// resolution; done lane-parallel per sample against a window of the last 64 samples it took ~2000 cycles per sample, next to
-// streaming waves on the same SIMD or not.
+// Measured (profiles/r03_experiments.md): done one sample at a time -- lane-parallel against a window of the last 64 samples, or by
+// scalar mask operations -- the retirement cost 1 000 - 2 000 cycles per sample and decided the run time.
 #pragma once
 
 #include "rrt_block.h"
@@ -37,7 +37,10 @@ namespace rrtdev {
 
 constexpr int PP_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
 constexpr uint32_t PP_TINY = 64;  // a tree of up to this many vertices is looked at as a whole, one vertex per lane (no cell streams)
-constexpr int PP_KB = 16;   // most heads retired in one pass
+#ifndef RRT_PIPE_KB
+#define RRT_PIPE_KB 16
+#endif
+constexpr int PP_KB = RRT_PIPE_KB;  // most heads retired in one pass (<= 32)
 constexpr int PP_WIN = 64;   // samples in flight ahead of retirement
 constexpr unsigned long long PP_STALL_TICKS = 200000000ull;  // 2 s of the 100 MHz wall clock
 constexpr int PP_RING = 64;  // ring of deposited samples (>= PP_WIN: the slot of sample s is written again for s + PP_RING, which is
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
     // retirement is a chain of ~100 dependent instructions per sample; next to three streaming waves it got one issue slot in
     // four, wave priority or not, and the twelve other waves waited for it.)
 #ifndef RRT_PIPE_MATES
-#define RRT_PIPE_MATES 0  // resolving waves that share the retiring wave's SIMD (0..3)
+#define RRT_PIPE_MATES 3  // resolving waves that share the retiring wave's SIMD (0..3; measured: profiles/r03_experiments.md)
 #endif
     bool idle = false;
     if (!retirer && L.simd_of[wave] == L.simd_of[RW]) {
