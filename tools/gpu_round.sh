@@ -69,7 +69,11 @@ prof)
         rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline --no-batched > $O/prof_c$c.json 2> $O/prof_c$c.err
         echo "prof c$c rc=$?"
         f=$(ls -t $O/prof_c$c/*/*kernel_stats.csv 2>/dev/null | head -n 1); [ -n "$f" ] && cp $f $O/config${c}_kernel_stats.csv
-    done ;;
+    done
+    # the one-CU-per-query pipeline (rrt_pipe_kernel): 256 x config 2
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2_q256 -- python3 $R/bench.py --queries 256 --steps 5 --warmup 1 --no-cpu-baseline --no-batched > $O/prof_c2_q256.json 2> $O/prof_c2_q256.err
+    echo "prof c2 q256 rc=$?"
+    f=$(ls -t $O/prof_c2_q256/*/*kernel_stats.csv 2>/dev/null | head -n 1); [ -n "$f" ] && cp $f $O/config2_q256_kernel_stats.csv ;;
 pmc)
     SPECS=("2 1" "3 1" "4 64" "2 8" "2 256" "5 256")
     for spec in "${SPECS[@]}"; do

@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-KERNELS = ("rrt_expand_block_kernel", "rrt_dubins_block_kernel", "rrt_expand_kernel")
+KERNELS = ("rrt_expand_block_kernel", "rrt_dubins_block_kernel", "rrt_pipe_kernel", "rrt_expand_kernel")
 SQ = ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU")
 
 
