@@ -156,6 +156,9 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
 #endif
 
 #ifdef RRT_STAMPS
+    unsigned long long sleep_iters = 0, nslept = 0;
+    bool slept_now = false;
+    unsigned long long res_t0 = 0, hist_n[5] = {0, 0, 0, 0, 0}, hist_c[5] = {0, 0, 0, 0, 0};
 #define DSTAMP(k)                                               \
     do {                                                        \
         unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -612,9 +615,20 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                     failed = true;
                     break;
                 }
+#ifdef RRT_STAMPS
+                sleep_iters += 1;
+                slept_now = true;
+#endif
                 __builtin_amdgcn_s_sleep(16);
             }
+#ifdef RRT_STAMPS
+            nslept += slept_now ? 1 : 0;
+            slept_now = false;
+#endif
             DSTAMP(4);  // (diagnostic build, wave 0) waiting
+#ifdef RRT_STAMPS
+            res_t0 = tstamp;
+#endif
             if (failed) break;
         }
         // =============================== resolve sample s against a snapshot ===============================
@@ -666,9 +680,12 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
             });
             uint32_t nn_d2 = ld2, nn_idx = lidx;
             wave_min_key_idx(nn_d2, nn_idx);
+            // nothing in the box, or something that a vertex outside the box could beat: the box once more at twice the size, then
+            // (a sample far from the tree: a region the tree has not reached, or cannot) every vertex in turn -- 4 bytes and six
+            // instructions per vertex, where ever larger boxes would deal out every record of the map
             int radn = rad0;
-            // nothing in the box, or something that a vertex outside the box could beat: double the box (nearest only)
-            while (jsnap > PP_TINY && (nn_d2 == NONE || nn_d2 > (uint32_t)radn * (uint32_t)radn) && radn < (W > H ? W : H)) {
+            bool far = jsnap > PP_TINY && (nn_d2 == NONE || nn_d2 > (uint32_t)radn * (uint32_t)radn) && radn < (W > H ? W : H);
+            if (far) {
                 radn = 2 * radn + 1;
                 ld2 = NONE;
                 lidx = NONE;
@@ -681,6 +698,34 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                     lvl = nearer ? rc.z : lvl;
                     lvh = nearer ? rc.w : lvh;
                 });
+                nn_d2 = ld2;
+                nn_idx = lidx;
+                wave_min_key_idx(nn_d2, nn_idx);
+                far = (nn_d2 == NONE || nn_d2 > (uint32_t)radn * (uint32_t)radn) && radn < (W > H ? W : H);
+            }
+            if (far) {
+                ld2 = NONE;
+                lidx = NONE;
+                for (uint32_t b0 = 0; b0 < jsnap; b0 += 256u) {
+                    uint32_t xy4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t k = b0 + 64u * (uint32_t)u + (uint32_t)lane;
+                        xy4[u] = nodes_g[k < jsnap ? k : 0u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {  // (a lane meets its vertices in index order: strict < keeps the lowest index)
+                        const uint32_t k = b0 + 64u * (uint32_t)u + (uint32_t)lane;
+                        const uint32_t d2 = k < jsnap ? dist2(xy4[u], xq) : NONE;
+                        const bool nearer = d2 < ld2;
+                        ld2 = nearer ? d2 : ld2;
+                        lidx = nearer ? k : lidx;
+                        lxy = nearer ? xy4[u] : lxy;
+                    }
+                }
+                const unsigned long long cbits = (unsigned long long)__double_as_longlong(vcost[lidx != NONE ? lidx : 0u]);
+                lvl = (uint32_t)cbits;
+                lvh = (uint32_t)(cbits >> 32);
                 nn_d2 = ld2;
                 nn_idx = lidx;
                 wave_min_key_idx(nn_d2, nn_idx);
@@ -784,6 +829,14 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
             }
         }
         DSTAMP(5);  // deposit
+#ifdef RRT_STAMPS
+        {  // how long this sample took its wave (wave 0's, and the retiring wave's resolutions): a slow head holds everybody up
+            const unsigned long long dt = tstamp - res_t0;
+            const int bk = dt < 20000ull ? 0 : dt < 40000ull ? 1 : dt < 80000ull ? 2 : dt < 160000ull ? 3 : 4;
+            hist_n[bk] += 1;
+            hist_c[bk] += dt;
+        }
+#endif
     }
     if (retirer) {
         __builtin_amdgcn_s_setprio(0);
@@ -851,6 +904,12 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
 #ifdef RRT_STAMPS
         for (int k = 0; k < 6; ++k) D->cyc[k] = cyc[k];
         for (int k = 0; k < 8; ++k) D->wcyc[k] = L.dbg[k];
+        for (int k = 0; k < 5; ++k) {
+            D->wcyc[8 + k] = hist_n[k];
+            D->wcyc[13 + k] = hist_c[k];
+        }
+        D->wcyc[18] = nslept;
+        D->wcyc[19] = sleep_iters;
 #endif
     }
 }

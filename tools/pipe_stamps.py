@@ -46,3 +46,6 @@ tot_r = (cyc[7] + one_cyc + cyc[9] + cyc[10]) or 1
 print("the retiring wave: waiting for the head %.1f %%, publishing %.1f %% (%d publications, %.0f cycles each), passes %.1f %% (%d passes, %.2f heads and %.0f cycles each), heads on their own %.1f %%" % (
     100.0 * cyc[9] / tot_r, 100.0 * cyc[10] / tot_r, cyc[13], cyc[10] / max(cyc[13], 1), 100.0 * cyc[7] / tot_r, passes, cyc[12] / max(passes, 1), cyc[7] / max(passes, 1),
     100.0 * one_cyc / tot_r))
+hn, hc = cyc[14:19], cyc[19:24]
+print("wave 0's samples by the time they took it (cycles): " + ", ".join("%s: %d (%.1f %% of its time)" % (nm, a_, 100.0 * c_ / max(sum(hc), 1)) for nm, a_, c_ in zip(("< 20 k", "20 - 40 k", "40 - 80 k", "80 - 160 k", "> 160 k"), hn, hc)))
+print("wave 0 found the window full for %d of its samples (%d sleeps)" % (cyc[24], cyc[25]))
