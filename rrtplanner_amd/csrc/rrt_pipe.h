@@ -411,7 +411,10 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
         rt_mark = __builtin_amdgcn_s_memtime();
 #endif
         for (;;) {
-            if (npend >= 16 || rh - pub_h >= 16 || rh >= n) {
+#ifndef RRT_PIPE_PUB
+#define RRT_PIPE_PUB 16  // samples retired between publications at most (a publication waits for the stores' acknowledgement)
+#endif
+            if (npend >= RRT_PIPE_PUB || rh - pub_h >= RRT_PIPE_PUB || rh >= n) {
                 publish();
                 RSTAMP(4);
                 if (rh >= n) return -1;
