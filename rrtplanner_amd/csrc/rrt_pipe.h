@@ -46,10 +46,10 @@ constexpr unsigned long long PP_STALL_TICKS = 200000000ull;  // 2 s of the 100 M
 constexpr int PP_RING = 64;  // ring of deposited samples (>= PP_WIN: the slot of sample s is written again for s + PP_RING, which is
                              // only taken once s has been retired)
 
-// One sample as its wave resolved it against its snapshot of the tree (128 bytes, 32 words: the retiring wave reads a record with
-// one LDS instruction, lane k word k).  The four masks are over the samples in flight since the snapshot, bit m & 63 for sample m
-// in [snap_i, s): what the retiring wave needs to know about them does not depend on whether they were inserted, so the
-// resolving wave works it out (the sample stream is an input, rrt.py:240) and the retirement is a few scalar operations.
+// One sample as its wave resolved it against its snapshot of the tree (128 bytes, 32 words).  The four masks are over the samples in
+// flight since the snapshot, bit m & 63 for sample m in [snap_i, s): what the retiring wave needs to know about them does not
+// depend on whether they were inserted, so the resolving wave works it out (the sample stream is an input, rrt.py:240) and the
+// retirement is mask arithmetic, one lane per sample.
 struct PpRec {
     uint32_t xq;
     uint32_t nn_idx, nn_d2;  // nearest vertex of the snapshot
@@ -71,7 +71,7 @@ struct PpRec {
     uint32_t pad1[8];
 };
 static_assert(sizeof(PpRec) == 128, "PpRec");
-// word numbers of the fields (the retiring wave's v_readlane)
+// word numbers of the fields (the retiring wave reads them by word: a pass one record per lane, a lone head one word per lane)
 constexpr int PW_XQ = 0, PW_NNIDX = 1, PW_NND2 = 2, PW_FLAGS = 3, PW_CELLSNN = 4, PW_HITS = 5, PW_VB = 6, PW_NLOS = 7, PW_CB = 8, PW_CCAND = 10,
               PW_SNAPI = 11, PW_READY = 12, PW_CCNT = 13, PW_NNMASK = 16, PW_DUPMASK = 18, PW_RMASK = 20, PW_CELLMASK = 22;
 
@@ -91,8 +91,8 @@ struct PpLds {
     uint32_t fail;                        // a wave waited PP_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
     uint32_t simd_of[NWAVE];              // which SIMD each wave runs on
     unsigned long long stat[5];
-    unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, the retiring wave's cycles [1] fast path [2] slow path (younger vertices in
-                                // the ball) [3] waiting for the head [4] publishing [5] next record, [6] heads retired, [7] publications
+    unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, the retiring wave's cycles [1] in passes [2] passes | cycles of heads
+                                // retired on their own << 24, [3] waiting for the head [4] publishing, [6] heads retired in passes, [7] publications
 };
 
 // conservative single-precision lower bound of vcost + sqrt(d2): below the f64 value by more than every rounding on the way, for
@@ -573,22 +573,18 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
         }
     };
     if (retirer) __builtin_amdgcn_s_setprio(3);
-#ifndef RRT_PIPE_SHARED_SIMD
-    // The retiring wave has its SIMD to itself: the other waves of the workgroup that landed there only join the barriers.  (The
-    // retirement is a chain of ~100 dependent instructions per sample; next to three streaming waves it got one issue slot in
-    // four, wave priority or not, and the twelve other waves waited for it.)
+    // RRT_PIPE_MATES (experiment, profiles/r03_experiments.md): how many resolving waves share the retiring wave's SIMD -- the others
+    // that landed there only join the barriers.  While the retirement cost ~2 000 cycles per sample, a SIMD of its own (0) paid for
+    // the three waves given up; with the passes it does not (3: every wave works).
 #ifndef RRT_PIPE_MATES
-#define RRT_PIPE_MATES 3  // resolving waves that share the retiring wave's SIMD (0..3; measured: profiles/r03_experiments.md)
+#define RRT_PIPE_MATES 3
 #endif
     bool idle = false;
-    if (!retirer && L.simd_of[wave] == L.simd_of[RW]) {
+    if (RRT_PIPE_MATES < 3 && !retirer && L.simd_of[wave] == L.simd_of[RW]) {
         int before = 0;  // waves of that SIMD with a lower number
         for (int w = 0; w < wave; ++w) before += (L.simd_of[w] == L.simd_of[RW]) ? 1 : 0;
         idle = before >= RRT_PIPE_MATES;
     }
-#else
-    const bool idle = false;
-#endif
 
     int wait_done = -1;  // bounded waiting of a resolving wave: the retired count when it began to wait, and when
     unsigned long long wait_t0 = 0;
