@@ -578,8 +578,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         for (int cbase = 0; cbase < ncr; cbase += 64) {
             uint32_t tcnt = 0, toff = 0;  // lane c: fill count and record offset of cell cbase + c
             if (cbase + lane < ncr) {
-                const int ci = cbase + lane, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
+                const int ci = cbase + lane, ccx = cx0 + ci / ny, ccy = cy0 + ci % ny, cell = ccx * ncy + ccy;
+#ifndef RRT_NO_CELL_CULL
+                // a cell beyond the radius holds no hit (the corners of the box)
+                const int xl = ccx << cshift, xh = xl + (1 << cshift) - 1, yl = ccy << cshift, yh = yl + (1 << cshift) - 1;
+                const int ddx = x < xl ? xl - x : (x > xh ? x - xh : 0), ddy = y < yl ? yl - y : (y > yh ? y - yh : 0);
+                tcnt = (uint32_t)(ddx * ddx + ddy * ddy) < r2h ? cellcnt[cell] : 0u;
+#else
                 tcnt = cellcnt[cell];
+#endif
                 toff = (uint32_t)cell * (uint32_t)ccap;
             }
             uint32_t incl = tcnt;
