@@ -269,6 +269,7 @@ struct BlockLds {
     double prevcost[PIPE ? NP : 1][PIPE ? 64 : 1];   // ... and (committer) the exact costs of the nodes they inserted
     uint32_t help_n[NWAVE], help_x[NWAVE];  // single-wave owners: open candidates of a blocked sample that all waves test together, its coordinates
     uint32_t help_any;
+    uint32_t slots[BSM == 16 ? NWAVE : 1][64];  // single-wave owners: the cell starts of a step of the near-set stream
     alignas(16) GSlot gslot[NWAVE];
     alignas(16) GCtl gctl[BSM];
 #ifdef RRT_STAMPS
@@ -305,6 +306,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #define RRT_CG16 2
 #endif
     constexpr int CG = (BSM == 16) ? (ROLE == ROLE_COMMIT ? 2 : RRT_CG16) : 1;
+#ifndef RRT_BLOCK_SCATTER
+#define RRT_BLOCK_SCATTER 1
+#endif
+    constexpr bool SCATTER = RRT_BLOCK_SCATTER && BSM == 16;  // (one wave streams a sample's whole ball: every call runs part 0 of 1)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
     auto &nnx = L.nnx;
     auto &brec = L.brec;
@@ -598,6 +603,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t pre = incl - tcnt;  // lanes past the last cell hold `total`: never <= a live record number
+            int cur_c = 0;  // (SCATTER) the cell the last step ended in
             for (uint32_t base = (uint32_t)part * (64u * CG); base < total; base += (uint32_t)nparts * (64u * CG)) {  // CG steps in flight
                 u32x4 rc[CG];
                 bool live[CG];
@@ -605,11 +611,33 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 for (int g2 = 0; g2 < CG; ++g2) {
                     const uint32_t idx = base + 64u * (uint32_t)g2 + (uint32_t)lane;
                     uint32_t lo = 0;  // the largest cell c with pre[c] <= idx (an empty cell shares its prefix with its successor)
+                    if constexpr (SCATTER) {
+                        // one wave walks the whole stream step by step: the cells that begin in this step write their number into the
+                        // slot of their first record (64 LDS words per wave), a running maximum over the lanes carries it on; the
+                        // lanes in front of the step's first cell start belong to the cell the last step ended in (rrt_pipe.h)
+                        volatile RRT_LDS uint32_t *slots = (volatile RRT_LDS uint32_t *)L.slots[wave];
+                        slots[lane] = NONE;
+                        const uint32_t rel = pre - (base + 64u * (uint32_t)g2);
+                        __builtin_amdgcn_wave_barrier();
+                        if (tcnt != 0u && rel < 64u) slots[rel] = (uint32_t)lane;
+                        __builtin_amdgcn_wave_barrier();
+                        int cv = (int)slots[lane];  // (NONE = -1)
+                        cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x111, 0xf, 0xf, false));
+                        cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x112, 0xf, 0xf, false));
+                        cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x114, 0xf, 0xf, false));
+                        cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x118, 0xf, 0xf, false));
+                        cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x142, 0xa, 0xf, false));
+                        cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x143, 0xc, 0xf, false));
+                        cv = cv < 0 ? cur_c : cv;
+                        cur_c = __builtin_amdgcn_readlane(cv, 63);
+                        lo = (uint32_t)cv;
+                    } else {
 #pragma unroll
-                    for (uint32_t bit = 32; bit != 0; bit >>= 1) {
-                        const uint32_t cand = lo + bit;
-                        const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cand << 2), (int)pre);
-                        lo = v <= idx ? cand : lo;
+                        for (uint32_t bit = 32; bit != 0; bit >>= 1) {
+                            const uint32_t cand = lo + bit;
+                            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cand << 2), (int)pre);
+                            lo = v <= idx ? cand : lo;
+                        }
                     }
                     const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
                     const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
