@@ -255,7 +255,7 @@ struct PipeShape {
 template <int G, int BSM, bool PIPE, bool INF>
 struct BlockLds {
     static constexpr int SB = BSM * G, NP = PipeShape<PIPE, INF>::NP;
-    alignas(16) u32x2 nnx[BSM * NWAVE];     // per own sample, per wave: {d2, idx}
+    alignas(16) u32x2 nnx[(BSM <= BS ? BSM : 1) * NWAVE];     // per own sample, per wave: {d2, idx} (phase A; not with more than 16 samples per member)
     alignas(16) BRec brec[PIPE ? 2 : 1][SB];  // (a pipelined committer: this block's records and the next one's)
     uint32_t xq_next[PIPE ? 64 : 1];        // pipelined committer: the next block's samples and whether its records are in
     uint32_t pre_state;
@@ -269,7 +269,8 @@ struct BlockLds {
     double prevcost[PIPE ? NP : 1][PIPE ? 64 : 1];   // ... and (committer) the exact costs of the nodes they inserted
     uint32_t help_n[NWAVE], help_x[NWAVE];  // single-wave owners: open candidates of a blocked sample that all waves test together, its coordinates
     uint32_t help_any;
-    uint32_t slots[BSM == 16 ? NWAVE : 1][64];  // single-wave owners: the cell starts of a step of the near-set stream
+    uint32_t tick;  // BSM > 16: the next sample of this member's share that a wave takes when it is through with its own
+    uint32_t slots[BSM >= 16 ? NWAVE : 1][64];  // single-wave owners: the cell starts of a step of the near-set stream
     alignas(16) GSlot gslot[NWAVE];
     alignas(16) GCtl gctl[BSM];
 #ifdef RRT_STAMPS
@@ -294,7 +295,13 @@ template <int G, int BSM, bool PIPE, bool INF, int ROLE, int CW = NWAVE>
 __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PIPE, INF> &L) {
     static_assert(CW == NWAVE || ROLE == ROLE_COMMIT, "only a committer runs with fewer waves");
     constexpr int NTG = CW * 64;  // threads of this workgroup
-    static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM <= BS && BSM * G <= 64, "team size");
+    static_assert(G >= 1 && G <= TEAM_MAX && BSM >= 1 && BSM * G <= 64, "team size");
+    // BSM > 16 (a pipelined team of 2 workers: 32 samples per member, 64 per super-block): one wave per sample as with 16, and a
+    // wave that is through takes the next of the member's samples off a counter; the hand-overs of a block are then shared by
+    // twice the samples.  (The owner phase is bound by the CU's vector issue, not by its slowest sample: 21 samples per member of
+    // a team of three took as long per sample as 16.)  No phase A: the launch only takes the variant when every query's
+    // near-set radius spans a cell (grid_nn).
+    constexpr bool WIDE = BSM > BS;
     static_assert(!PIPE || G > 1, "a pipeline needs a team");
     static_assert(PIPE == (ROLE != ROLE_ALL), "roles are the halves of a pipelined team");
     constexpr int LAG = PipeShape<PIPE, INF>::LAG, NP = PipeShape<PIPE, INF>::NP, NSLOT = PipeShape<PIPE, INF>::NSLOT;
@@ -305,11 +312,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #ifndef RRT_CG16
 #define RRT_CG16 2
 #endif
-    constexpr int CG = (BSM == 16) ? (ROLE == ROLE_COMMIT ? 2 : RRT_CG16) : 1;
+    constexpr int CG = (BSM >= 16) ? (ROLE == ROLE_COMMIT ? 2 : RRT_CG16) : 1;
 #ifndef RRT_BLOCK_SCATTER
 #define RRT_BLOCK_SCATTER 1
 #endif
-    constexpr bool SCATTER = RRT_BLOCK_SCATTER && BSM == 16;  // (one wave streams a sample's whole ball: every call runs part 0 of 1)
+    constexpr bool SCATTER = RRT_BLOCK_SCATTER && BSM >= 16;  // (one wave streams a sample's whole ball: every call runs part 0 of 1)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [node cache | cell fill counts]
     auto &nnx = L.nnx;
     auto &brec = L.brec;
@@ -325,7 +332,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     auto &prevcost = L.prevcost;
     auto &gslot = L.gslot;
     auto &gctl = L.gctl;
-    constexpr int WPS = NWAVE / BSM;  // waves per sample in the owner phase
+    constexpr int WPS = BSM >= 16 ? 1 : NWAVE / BSM;  // waves per sample in the owner phase
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     int q = (int)blockIdx.x, g_ = 0;  // query, team member
     if (G > 1) {
@@ -347,9 +354,10 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // pre-scan (team members, RRTStandard / RRTStar): while member 0 commits block s, a member already scans the snapshot of
     // block s for the samples of block s + 1; after the commit only the steps that hold the new nodes are scanned again
     int pre_i = -1, pre_j = 0;  // the iteration the pre-scan is for, the node count it covered
-    uint32_t pre_xv = 0, pre_best[BSM];
+    constexpr int BSA = WIDE ? 1 : BSM;  // samples of phase A (none where a member takes more than 16)
+    uint32_t pre_xv = 0, pre_best[BSA];
 #pragma unroll
-    for (int k = 0; k < BSM; ++k) pre_best[k] = NONE;
+    for (int k = 0; k < BSA; ++k) pre_best[k] = NONE;
     bool team_failed = false;
     u64 A_prev[NP];  // pipelined committer: the samples of the previous block(s) that were inserted, and the node count before each
     int jp0[NP];
@@ -386,7 +394,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // two cells -- there the stream only serves the nearest-neighbour search (every tree keeps its nodes in the cell records).
     // (Only where one wave resolves a sample, i.e. teams of up to 4 workers and single CUs: the many-query shapes.  A single
     // RRTStandard query on a big team is bound by its committer, which would only pay for the records: measured 5.08 -> 5.27 ms.)
-    const bool cells_on = star || BSM == 16;
+    const bool cells_on = star || BSM >= 16;
     const uint32_t r2h = star ? r2 : (cells_on ? (uint32_t)((2 << cshift) * (2 << cshift)) : 0u);
     int rad = 0;  // largest |dx| with dx*dx < r2h
     if (r2h > 0) {
@@ -480,7 +488,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // Where one wave resolves a sample (BSM == 16) the first 256 entries of its list live in LDS, the rest in HBM: a sample whose
     // two cheapest candidates are blocked reads its list back several times, and that sample is the one its whole block waits
     // for.  Groups of waves (each with a share of the ball) keep their lists in HBM.
-    constexpr bool LDSLIST = BSM == 16;
+    constexpr bool LDSLIST = BSM >= 16;
     const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE * (G + (PIPE ? 1 : 0))));  // the engine sizes the spill area per team member
     u32x4 *const clist_base = reinterpret_cast<u32x4 *>(spill) + (size_t)(g * NWAVE) * (size_t)clist_cap;  // this member's 16 lists (and go2goal's scratch)
     u32x4 *const clist = clist_base + (size_t)wave * (size_t)clist_cap;
@@ -879,7 +887,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // the ball holds a node.  The brute-force scan of the node array (phase A) then never runs; a sample whose ball is empty --
     // the first samples of a run, pockets the tree has not reached -- gets its nearest from one wave's own pass over the nodes.
     // Used when the radius spans at least a cell; smaller radii keep phase A (the ball is empty too often).
-    const bool grid_nn = rad >= 16;  // (RRTStandard: always, its stream radius is two cells of at least 16 pixels)
+    const bool grid_nn = WIDE || rad >= 16;  // (RRTStandard: always, its stream radius is two cells of at least 16 pixels)
+    if (WIDE && rad < 16) {  // (the launch does not take these variants for such a query; should it: leave at once, the one-CU kernel continues)
+        if (t == 0 && g_ == 0) D->status = ST_TEAM_FAIL;
+        return;
+    }
     // what snapshot_parent does behind its stream, for a stream that ran without the bound
     // amin (only meaningful when no parent is found): a lower bound of the cheapest entry at or above the bound -- the stream ran
     // without the bound, so its two cheapest entries are the two cheapest of the whole ball.  The committer needs it when a node
@@ -959,7 +971,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 
     // steps [c0, c1) of the scan: 4096 nodes per step, from the LDS cache or (beyond it) from HBM, next step prefetched
     const uint32_t node0 = xs;  // node 0 = the start
-    auto scan_steps = [&](int c0, int c1, int jlim, const uint32_t (&xs16)[BSM], uint32_t (&best)[BSM]) {
+    auto scan_steps = [&](int c0, int c1, int jlim, const uint32_t (&xs16)[BSA], uint32_t (&best)[BSA]) {
 #ifdef RRT_EXP_SCAN1
         c1 = c1 > 1 ? 1 : c1;  // timing experiment only (wrong trees): what the run costs without the brute-force scan
 #endif
@@ -969,7 +981,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             for (int c = c0; c < nl; ++c) {
                 u32x4 nxt = cur;
                 if (c + 1 < nl) nxt = nodes_lds4[(c + 1) * TPB + t];
-                block_scan_step<BSM>(cur, xs16, best, (uint32_t)c << 2);
+                block_scan_step<BSA>(cur, xs16, best, (uint32_t)c << 2);
                 cur = nxt;
             }
         }
@@ -986,7 +998,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     if (base + 2 >= jlim) cur.z = node0;
                     if (base + 3 >= jlim) cur.w = node0;
                 }
-                block_scan_step<BSM>(cur, xs16, best, (uint32_t)c << 2);
+                block_scan_step<BSA>(cur, xs16, best, (uint32_t)c << 2);
                 cur = nxt;
             }
         }
@@ -1096,9 +1108,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         }
         if (!worker && t < SB) xq_lds[t] = xv;  // a pipelined team's committer: nothing to resolve
         if (worker && !void_blk) {
-        uint32_t xs16[BSM];
+        uint32_t xs16[BSA];
 #pragma unroll
-        for (int k = 0; k < BSM; ++k) {  // this member's samples [BSM wg, BSM (wg + 1))
+        for (int k = 0; k < BSA; ++k) {  // this member's samples [BSM wg, BSM (wg + 1))
             const int sk = wg * BSM + k;
             uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)xv, sk);
             if (sk >= nb) X = (uint32_t)__builtin_amdgcn_readlane((int)xv, 0);
@@ -1109,22 +1121,22 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         //                  the record stream) ----------------
         const int nsteps = (j0 + CHUNK - 1) / CHUNK;
         if (!grid_nn) {
-            uint32_t best[BSM];
+            uint32_t best[BSA];
             int c_first = 0;
             if (G > 1 && pre_i == i0) {  // steps [0, pre_j) were scanned while member 0 committed; unfilled slots held node 0
                 c_first = pre_j / CHUNK;
 #pragma unroll
-                for (int k = 0; k < BSM; ++k) best[k] = pre_best[k];
+                for (int k = 0; k < BSA; ++k) best[k] = pre_best[k];
             } else {
 #pragma unroll
-                for (int k = 0; k < BSM; ++k) best[k] = NONE;
+                for (int k = 0; k < BSA; ++k) best[k] = NONE;
             }
             scan_steps(c_first, nsteps, j0, xs16, best);
             // per sample: wave minimum of d2, lowest index among the lanes that hold it (a lane's best key already
             // carries its lowest such index); gathered into lanes 0..15
             uint32_t gd = NONE, gi = NONE;
 #pragma unroll
-            for (int k = 0; k < BSM; ++k) {
+            for (int k = 0; k < BSA; ++k) {
                 const uint32_t key = best[k];
                 const uint32_t d2m = wave_min_u32(key) >> 8;
                 const uint32_t tag = key & 0xffu;
@@ -1139,12 +1151,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     gi = ki;
                 }
             }
-            if (lane < BSM) {
+            if (lane < BSA) {
                 u32x2 v = {gd, gi};
                 ((RRT_LDS u32x2 *)nnx)[lane * NWAVE + wave] = v;
             }
         }
         if (t < SB) xq_lds[t] = xv;  // lane s: sample s (s < nb)
+        if (WIDE && t == 0) L.tick = NWAVE;
         STAMP(0);
         __syncthreads();
         STAMP(1);
@@ -1154,8 +1167,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
         uint32_t my_open = 0, my_ntests = 0, my_tcells = 0;  // single-wave owner of a blocked sample: see below
+        int my_sidx = -1;  // the blocked sample whose candidates wait in this wave's list
+        auto take_ticket = [&]() -> int {
+            uint32_t tk = 0;
+            if (lane == 0) tk = __hip_atomic_fetch_add(&L.tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return __builtin_amdgcn_readfirstlane((int)tk);
+        };
+        for (int pass = 0;; ++pass) {  // (once, except WIDE with samples left behind blocked ones)
+        my_open = 0;
         if constexpr (WPS == 1) {
-        const int sidx = wg * BSM + wave;  // the sample this wave owns (waves BSM.. of a small-BSM team member idle here)
 #ifdef RRT_EXP_PRIO
         // the arbiter issues the oldest wave first: without help the owners of the later samples of a SIMD fall behind and
         // everybody waits for them at the barrier
@@ -1167,8 +1187,14 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // of the workgroup test them, four lines of sight per wave and memory round trip (one wave on its own walks them lane by
         // lane, four round trips, while the other fifteen wait for it: it was a third of a single-wave owner's block).
         const bool coop = grid_nn && rad < 64;  // (every candidate segment shorter than 64 cells)
-        if (wave < BSM && sidx < nb) {
-            const int k = wave;
+        // wave k resolves sample k of the member's share; with more than 16 samples per member (WIDE) whoever is through takes the
+        // next one off L.tick -- except a wave that holds a blocked sample: its list has to stay as it is until all waves have
+        // tested the candidates (behind the barrier), after which the waves come back for whatever is left of the share
+        int k = wave;
+        if (WIDE && pass > 0) k = take_ticket();
+        for (; k < BSM;) {
+            const int sidx = wg * BSM + k;
+            if (sidx >= nb) break;
             const uint32_t Xk = (uint32_t)__builtin_amdgcn_readlane((int)xv, sidx);  // every wave holds the same xv
             uint32_t d2s = NONE, vs = NONE;
             Top2 tt0;
@@ -1231,6 +1257,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (star && nnear0 != 0) finish_parent(Xk, j0, cnear_s, tt0, nlist0, pc, pi, ntests, tcells, amin, coop, my_open);
                 my_ntests = ntests;
                 my_tcells = tcells;
+                if (my_open != 0) my_sidx = sidx;
                 if (my_open != 0 && lane == 0) {
                     L.help_n[wave] = my_open;
                     L.help_x[wave] = Xk;
@@ -1270,6 +1297,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 brec[0][sidx] = r;
             }
+            if (!WIDE || my_open != 0) break;
+            k = take_ticket();
         }
 #ifdef RRT_EXP_PRIO
         __builtin_amdgcn_s_setprio(0);
@@ -1568,7 +1597,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     }
                     count_tests(my_open, wc, wi, my_ntests, my_tcells);
                     if (lane == 0) {
-                        BRec &r = brec[0][wg * BSM + wave];
+                        BRec &r = brec[0][my_sidx];
                         if (wi != NONE) {
                             r.cbest = wc;
                             r.vbest = wi;
@@ -1582,6 +1611,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 __syncthreads();
             }
         }
+        if (!WIDE) break;
+        const int taken = (int)uni32(L.tick);  // (every wave reads it before any wave takes another ticket)
+        __syncthreads();
+        if (taken >= nb - wg * BSM) break;  // every sample of the share has been taken (its wave is past the barrier: resolved)
+        }  // pass
         STAMP(3);
         }  // worker
 
@@ -1609,9 +1643,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 pre_j = j0;
                 const int nbn = (n - pre_i) < SB ? (n - pre_i) : SB;
                 pre_xv = lane < nbn ? at32(samples, (uint32_t)(pre_i + lane)) : 0u;
-                uint32_t xsn[BSM];
+                uint32_t xsn[BSA];
 #pragma unroll
-                for (int k = 0; k < BSM; ++k) {
+                for (int k = 0; k < BSA; ++k) {
                     const int sk = wg * BSM + k;
                     uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)pre_xv, sk);
                     if (sk >= nbn) X = (uint32_t)__builtin_amdgcn_readlane((int)pre_xv, 0);
@@ -1703,9 +1737,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 pre_j = j0;
                 const int nbn = (n - pre_i) < SB ? (n - pre_i) : SB;
                 pre_xv = lane < nbn ? samples[pre_i + lane] : 0u;
-                uint32_t xsn[BSM];
+                uint32_t xsn[BSA];
 #pragma unroll
-                for (int k = 0; k < BSM; ++k) {
+                for (int k = 0; k < BSA; ++k) {
                     const int sk = g * BSM + k;
                     uint32_t X = (uint32_t)__builtin_amdgcn_readlane((int)pre_xv, sk);
                     if (sk >= nbn) X = (uint32_t)__builtin_amdgcn_readlane((int)pre_xv, 0);

@@ -97,6 +97,7 @@ struct rrt_batch {
     bool last_inf = false;      // the last launch ran the Informed instantiation
     bool split = false;         // the last launch ran committers and workers as two kernels (RRT_FLAG_SPLIT_COMMIT)
     bool last_pipe1 = false;    // the last launch ran the barrier-free one-CU kernel (rrt_pipe.h)
+    bool last_wide = false;     // the last launch ran a team variant with more than 16 samples per member
     int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
     int32_t team_qpad = 0;      // Q rounded up to a multiple of 8: block = member * team_qpad + query
     int32_t team_want = TEAM_MAX;  // the caller's cap on the team size
@@ -793,8 +794,11 @@ static BatchView make_view(rrt_batch *b) {
 
 typedef void (*block_kernel_fn)(BatchView);
 
+// wide: a pipelined team of 2 workers with 32 samples per member (rrt_block.h, BSM > 16).  Measured (profiles/r03_experiments.md):
+// config 4's query on 2 + 1 CUs 8.92 -> 7.87 ms; three workers with 21 samples each gained nothing (6.32 vs 6.25 ms) and are not built.
 template <bool INF>
-static block_kernel_fn block_kernel_fn_inf(int team, bool pipe) {
+static block_kernel_fn block_kernel_fn_inf(int team, bool pipe, bool wide) {
+    if (pipe && wide && team == 2) return rrt_expand_block_kernel<2, 32, true, INF>;
     if (pipe) {
         switch (team) {
             case 64: return rrt_expand_block_kernel<64, 1, true, INF>;
@@ -817,11 +821,13 @@ static block_kernel_fn block_kernel_fn_inf(int team, bool pipe) {
     }
 }
 
-static block_kernel_fn block_kernel_fn_of(int team, bool pipe, bool inf) {
-    return inf ? block_kernel_fn_inf<true>(team, pipe) : block_kernel_fn_inf<false>(team, pipe);
+static block_kernel_fn block_kernel_fn_of(int team, bool pipe, bool inf, bool wide = false) {
+    return inf ? block_kernel_fn_inf<true>(team, pipe, wide) : block_kernel_fn_inf<false>(team, pipe, wide);
 }
 
-static const void *block_kernel_of(int team, bool pipe, bool inf) { return reinterpret_cast<const void *>(block_kernel_fn_of(team, pipe, inf)); }
+static const void *block_kernel_of(int team, bool pipe, bool inf, bool wide = false) {
+    return reinterpret_cast<const void *>(block_kernel_fn_of(team, pipe, inf, wide));
+}
 
 // static LDS of the kernels a batch of this team size may launch: its own variants and the one-CU kernel that continues
 // a batch after a hand-off timed out (rrt_batch_sync)
@@ -833,8 +839,11 @@ static size_t block_kernel_static_lds(int team) {
             for (bool inf : {false, true}) {
                 if (g > team || (pipe && g < 2)) continue;
                 if (!pipe && g == 3) continue;  // (three workers exist only as a pipelined team)
-                if (hipFuncGetAttributes(&a, block_kernel_of(g, pipe, inf)) != hipSuccess) return 16384;
-                worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+                for (bool wide : {false, true}) {
+                    if (wide && !(pipe && g == 2)) continue;
+                    if (hipFuncGetAttributes(&a, block_kernel_of(g, pipe, inf, wide)) != hipSuccess) return 16384;
+                    worst = a.sharedSizeBytes > worst ? a.sharedSizeBytes : worst;
+                }
             }
     return (worst + 255) & ~(size_t)255;
 }
@@ -899,6 +908,17 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         bool inf = false;  // any Informed query in this launch?
         for (const QDesc &d : b->h_desc)
             if (d.status == ST_RUNNING && d.alg == 2) inf = true;
+#ifndef RRT_NO_WIDE
+        // a pipelined team of 2 workers: 32 samples per member instead of 16 (the waves that are through take the extra ones; the
+        // hand-overs of a block are shared by 64 samples instead of 32) -- unless a query's near-set radius is below a cell (that
+        // variant has no brute-force scan)
+        bool wide = pipe && !inf && team == 2;
+        for (const QDesc &d : b->h_desc)
+            if (d.status == ST_RUNNING && d.alg != RRT_ALG_STANDARD && d.r2_rewire < 257u) wide = false;
+#else
+        const bool wide = false;
+#endif
+        b->last_wide = wide;
         b->last_team = team;
         b->last_inf = inf;
         b->last_pipe1 = false;
@@ -914,7 +934,7 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
             b->timed = true;
             return RRT_OK;
         }
-        HIPCHK(ctx, raise_dynamic_lds(ctx->device, block_kernel_of(team, pipe, inf), (int)blk_lds_bytes));
+        HIPCHK(ctx, raise_dynamic_lds(ctx->device, block_kernel_of(team, pipe, inf, wide), (int)blk_lds_bytes));
         hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
         if (team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
@@ -940,7 +960,7 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             b->split = true;
         } else {
-            hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf), tg, dim3(TPB), blk_lds_bytes, ctx->stream, v);
+            hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf, wide), tg, dim3(TPB), blk_lds_bytes, ctx->stream, v);
         }
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
@@ -1041,7 +1061,7 @@ extern "C" int rrt_batch_kernel_name(rrt_batch *b, char *buf, int32_t len) {
     char tmp[160];
     if (b->use_block) {
         const int team = b->last_team > 0 ? b->last_team : b->team;
-        const int bsm = team <= 4 ? 16 : 64 / team;
+        const int bsm = b->last_wide ? 32 : (team <= 4 ? 16 : 64 / team);
         if (b->last_pipe1) snprintf(tmp, sizeof tmp, "rrt_pipe_kernel");
         else if (b->split) snprintf(tmp, sizeof tmp, "rrt_block_work_kernel<%d, %d, false> + rrt_block_commit_kernel<%d, %d, false>", team, bsm, team, bsm);
         else snprintf(tmp, sizeof tmp, "rrt_expand_block_kernel<%d, %d, %s, %s>", team, bsm, (team > 1 && b->pipe) ? "true" : "false", b->last_inf ? "true" : "false");
