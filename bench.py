@@ -186,7 +186,6 @@ def main():
     ap.add_argument("--team", type=int, default=None, choices=[1, 2, 3, 4, 8, 16, 32, 64],
                     help="cap on the CUs per query (default: the largest team for which all teams are resident together)")
     ap.add_argument("--serial", action="store_true", help="the one-sample-per-iteration kernel (RRT_FLAG_SERIAL), for comparison")
-    ap.add_argument("--split", action="store_true", help="experiment: committer and workers of a single query's team as two kernels (RRT_FLAG_SPLIT_COMMIT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the informational batched leg (configs[3] share of one GPU)")
     ap.add_argument("--rewire-leg", action="store_true", help="add an informational leg: query 0 with the opt-in true rewire (not the reference's behaviour)")
@@ -234,7 +233,7 @@ def main():
         multi.init_comm(ctx, rank, world)  # RCCL communicator (ncclCommInitRank), id handed over on local tmpfs
     ctx.set_grid(og8)
     dubins = alg >= _ffi.ALG_DUBINS
-    batch = _ffi.Batch(ctx, Q, n, team=args.team, dubins=dubins, serial=args.serial, split=args.split)
+    batch = _ffi.Batch(ctx, Q, n, team=args.team, dubins=dubins, serial=args.serial)
     keep, rngs, states, dub_inputs = [], [], [], []
     for slot in range(Q):
         g = rank + world * slot

@@ -60,9 +60,6 @@ extern "C" {
 #define RRT_FLAG_DUBINS 64u /* the batch runs Dubins queries (RRT_ALG_DUBINS / RRT_ALG_DUBINS_STAR) only, one CU per query: 16 samples per
                               round on per-node headings and cell records (rrt_dubins_block.h); with RRT_FLAG_SERIAL the
                               one-sample-per-iteration kernel, kept as a cross-check.  rrt_plan sets it by itself for such a query. */
-#define RRT_FLAG_SPLIT_COMMIT 128u /* experiment (profiles/r03_experiments.md): a single query's pipelined team of 64 workers as TWO kernels on two
-                                     streams of the context -- the committer as a workgroup of 8 waves compiled for 256 vector registers,
-                                     the workers without the committer's code.  Results are the same; off by default. */
 #define RRT_FLAG_NOPIPE1 32768u /* one CU per query, RRTStandard / RRTStar: the 16-samples-per-pass block kernel instead of the barrier-free
                                   pipeline (rrt_pipe.h); kept as a cross-check, the results are the same */
 #define RRT_FLAG_TEAM_MAX(g) ((uint32_t)(g) << 8) /* cap the team size at g CUs per query (g = 2, 4, ... 64; 0 = no cap) */

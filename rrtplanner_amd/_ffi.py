@@ -31,18 +31,16 @@ FLAG_TEAM_FAULT = 8
 FLAG_NOPIPE = 16
 FLAG_REWIRE = 32
 FLAG_DUBINS = 64
-FLAG_SPLIT_COMMIT = 128
 FLAG_NOPIPE1 = 32768
 
 
-def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=True, rewire=False, dubins=False, split=False, pipe1=True):
+def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=True, rewire=False, dubins=False, pipe1=True):
     """flags word of rrt_plan / rrt_batch_create.  team: None = as many CUs per query as fit (up to 64), 1 = one CU,
     2..64 = cap on the team's workers; pipe = False: no pipelined teams (workers + one committing CU); team_fault = the
     fault-injection flag of the tests."""
     f = (FLAG_LOGS if logs else 0) | (FLAG_SERIAL if serial else 0) | (FLAG_TEAM_FAULT if team_fault else 0) | (0 if pipe else FLAG_NOPIPE)
     f |= FLAG_REWIRE if rewire else 0  # the opt-in true rewire (not the reference's behaviour)
     f |= FLAG_DUBINS if dubins else 0
-    f |= FLAG_SPLIT_COMMIT if split else 0  # experiment: committer and workers of a 64-worker team as two kernels
     f |= 0 if pipe1 else FLAG_NOPIPE1  # one CU per query: the block kernel instead of the barrier-free pipeline (a cross-check)
     if team == 1:
         f |= FLAG_NOTEAM
@@ -428,10 +426,10 @@ class Batch:
     """Q independent queries resident on the device (rrt_batch_*)."""
 
     def __init__(self, ctx: Context, Q: int, n_cap: int, logs: bool = False, serial: bool = False, team=None, team_fault: bool = False,
-                 pipe: bool = True, rewire: bool = False, dubins: bool = False, split: bool = False, pipe1: bool = True):
+                 pipe: bool = True, rewire: bool = False, dubins: bool = False, pipe1: bool = True):
         self.ctx, self.Q, self.n_cap, self.logs, self.dubins = ctx, int(Q), int(n_cap), logs, dubins
         self._h = C.c_void_p()
-        flags = kernel_flags(logs, serial, team, team_fault, pipe, rewire, dubins, split, pipe1)
+        flags = kernel_flags(logs, serial, team, team_fault, pipe, rewire, dubins, pipe1)
         _check(ctx.handle, lib().rrt_batch_create(ctx.handle, self.Q, self.n_cap, flags, C.byref(self._h)))
         if not hasattr(ctx, "_batches"):
             ctx._batches = weakref.WeakSet()

@@ -289,8 +289,8 @@ constexpr int ROLE_ALL = 0, ROLE_COMMIT = 1, ROLE_WORK = 2;
 // by then).
 // INF: the batch may hold Informed queries (alg 2); without it everything the ellipse needs is compiled out.
 
-// CW: waves of THIS workgroup.  16 everywhere, except for a pipelined team's committer launched as a kernel of its own
-// (rrt_block_commit_kernel, RRT_FLAG_SPLIT_COMMIT): 8 waves, so that it is compiled for 256 instead of 128 vector registers.
+// CW: waves of THIS workgroup (16; round 3 measured a committer of 8 waves as a kernel of its own, compiled for 256 vector registers:
+// no gain, profiles/r03_experiments.md -- the parameter stays, the kernels went).
 template <int G, int BSM, bool PIPE, bool INF, int ROLE, int CW = NWAVE>
 __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PIPE, INF> &L) {
     static_assert(CW == NWAVE || ROLE == ROLE_COMMIT, "only a committer runs with fewer waves");
@@ -2490,8 +2490,14 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #endif
 }
 
+// (RRT_BLOCK_DECL_ONLY: a translation unit that only launches the kernel; csrc/kernels_tu.hip holds the instantiations, dealt to
+//  several translation units so that they compile side by side)
 template <int G, int BSM, bool PIPE, bool INF>
-__global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
+__global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv)
+#ifdef RRT_BLOCK_DECL_ONLY
+    ;
+#else
+{
     __shared__ BlockLds<G, BSM, PIPE, INF> L;
     if constexpr (PIPE) {
 #if defined(RRT_ONLY_ROLE) && RRT_ONLY_ROLE == 1  // (resource analysis of one role; never run)
@@ -2506,19 +2512,6 @@ __global__ __launch_bounds__(TPB) void rrt_expand_block_kernel(BatchView bv) {
         rrt_block_body<G, BSM, PIPE, INF, ROLE_ALL>(bv, L);
     }
 }
-
-// RRT_FLAG_SPLIT_COMMIT: the two halves of a pipelined team as two kernels on two streams of the context.  Register allocation is
-// per kernel: the committer, 8 waves, gets 256 vector registers instead of the 128 of a 16-wave workgroup (the one-kernel form
-// spills 33 of them, profiles/r02_resource_usage_role1_committer.txt); the workers are compiled without the committer's code.
-template <int G, int BSM, bool INF>
-__global__ __launch_bounds__(512) void rrt_block_commit_kernel(BatchView bv) {
-    __shared__ BlockLds<G, BSM, true, INF> L;
-    rrt_block_body<G, BSM, true, INF, ROLE_COMMIT, 8>(bv, L);
-}
-template <int G, int BSM, bool INF>
-__global__ __launch_bounds__(TPB) void rrt_block_work_kernel(BatchView bv) {
-    __shared__ BlockLds<G, BSM, true, INF> L;
-    rrt_block_body<G, BSM, true, INF, ROLE_WORK>(bv, L);  // launched with bv.member0 = 1
-}
+#endif
 
 }  // namespace rrtdev

@@ -15,11 +15,14 @@
 #include <tuple>
 #include <vector>
 
+// The expansion kernels are only LAUNCHED from this translation unit; kernels_tu.hip holds their definitions, dealt to several
+// translation units that compile side by side (the single unit of round 3 took two and a half minutes).
+#define RRT_BLOCK_DECL_ONLY
+#define RRT_SERIAL_DECL_ONLY
 #include "rrt_hip.h"
 #include "rrt_kernels.h"
 #include "rrt_block.h"
-#include "rrt_dubins_block.h"
-#include "rrt_pipe.h"
+#include "rrt_kernel_decls.h"
 #include "rrt_prims.h"
 
 using namespace rrtdev;
@@ -59,8 +62,6 @@ struct PinnedDescs {
 struct rrt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // RRT_FLAG_SPLIT_COMMIT: the committers' kernel runs here, next to the workers' on `stream`
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint8_t *og = nullptr;      // active grid, device (W,H): og_buf + frame * W * H
     uint8_t *og_buf = nullptr;  // allocation holding 1 uploaded grid or `nframes` generated grids
     size_t og_buf_bytes = 0;
@@ -95,7 +96,6 @@ struct rrt_batch {
     bool pipe = false;          // the last launch ran the pipelined team kernel
     int32_t last_team = 0;      // workers per query of the last launch (1 after a hand-off timed out)
     bool last_inf = false;      // the last launch ran the Informed instantiation
-    bool split = false;         // the last launch ran committers and workers as two kernels (RRT_FLAG_SPLIT_COMMIT)
     bool last_pipe1 = false;    // the last launch ran the barrier-free one-CU kernel (rrt_pipe.h)
     bool last_wide = false;     // the last launch ran a team variant with more than 16 samples per member
     int32_t team_fallbacks = 0; // launches repeated with one CU per query after a team hand-off timed out
@@ -230,9 +230,6 @@ extern "C" int rrt_ctx_destroy(rrt_ctx *ctx) {
     if (ctx->single) rrt_batch_destroy(ctx->single);
     (void)rrt_comm_destroy(ctx);
     if (ctx->og_buf) (void)hipFree(ctx->og_buf);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RRT_OK;
@@ -798,7 +795,9 @@ typedef void (*block_kernel_fn)(BatchView);
 // config 4's query on 2 + 1 CUs 8.92 -> 7.87 ms; three workers with 21 samples each gained nothing (6.32 vs 6.25 ms) and are not built.
 template <bool INF>
 static block_kernel_fn block_kernel_fn_inf(int team, bool pipe, bool wide) {
-    if (pipe && wide && team == 2) return rrt_expand_block_kernel<2, 32, true, INF>;
+    if constexpr (!INF) {  // (the launch never takes the wide team for a batch with Informed queries)
+        if (pipe && wide && team == 2) return rrt_expand_block_kernel<2, 32, true, false>;
+    }
     if (pipe) {
         switch (team) {
             case 64: return rrt_expand_block_kernel<64, 1, true, INF>;
@@ -925,8 +924,7 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         if (team == 1 && !inf && !continuation && !(b->flags & RRT_FLAG_NOPIPE1)) {
             // one CU per query, RRTStandard / RRTStar: the barrier-free pipeline (rrt_pipe.h; static LDS only)
             b->last_pipe1 = true;
-            b->split = false;
-            hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+            hipLaunchKernelGGL(rrt_init_kernel<0>, ig, dim3(256), 0, ctx->stream, v);
             HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
             hipLaunchKernelGGL(rrt_pipe_kernel, dim3((unsigned)b->Q), dim3(TPB), 0, ctx->stream, v);
             HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
@@ -935,33 +933,11 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
             return RRT_OK;
         }
         HIPCHK(ctx, raise_dynamic_lds(ctx->device, block_kernel_of(team, pipe, inf, wide), (int)blk_lds_bytes));
-        hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+        hipLaunchKernelGGL(rrt_init_kernel<0>, ig, dim3(256), 0, ctx->stream, v);
         if (team > 1) HIPCHK(ctx, hipMemsetAsync(b->d_team, 0, (size_t)b->Q * TEAM_BYTES, ctx->stream));  // every polled word, every launch
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
         const dim3 tg(team > 1 ? (unsigned)(v.team_qpad * (team + (pipe ? 1 : 0))) : (unsigned)b->Q);
-        b->split = false;
-        if ((b->flags & RRT_FLAG_SPLIT_COMMIT) && pipe && team == 64 && !inf) {
-            // the committers as a kernel of their own (8 waves, 256 vector registers) on a second stream, the workers on the first:
-            // fork behind the init kernel and the memset, join in front of the read-back
-            if (!ctx->stream2) {
-                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-            }
-            HIPCHK(ctx, raise_dynamic_lds(ctx->device, reinterpret_cast<const void *>(rrt_block_commit_kernel<64, 1, false>), (int)blk_lds_bytes));
-            HIPCHK(ctx, raise_dynamic_lds(ctx->device, reinterpret_cast<const void *>(rrt_block_work_kernel<64, 1, false>), (int)blk_lds_bytes));
-            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            hipLaunchKernelGGL((rrt_block_commit_kernel<64, 1, false>), dim3((unsigned)v.team_qpad), dim3(512), blk_lds_bytes, ctx->stream2, v);
-            BatchView vw = v;
-            vw.member0 = 1;
-            hipLaunchKernelGGL((rrt_block_work_kernel<64, 1, false>), dim3((unsigned)(v.team_qpad * team)), dim3(TPB), blk_lds_bytes, ctx->stream, vw);
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            b->split = true;
-        } else {
-            hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf, wide), tg, dim3(TPB), blk_lds_bytes, ctx->stream, v);
-        }
+        hipLaunchKernelGGL(block_kernel_fn_of(team, pipe, inf, wide), tg, dim3(TPB), blk_lds_bytes, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
         HIPCHK(ctx, hipGetLastError());
         b->timed = true;
@@ -971,7 +947,7 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     b->claimed_cus = b->Q < ctx->num_cu ? b->Q : ctx->num_cu;  // one workgroup per query: no co-residency needed, the CUs are busy all the same
     (void)cu_claim(ctx->device, ctx->num_cu, b->claimed_cus, b->claimed_cus);
     if (b->dub_block) {
-        hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+        hipLaunchKernelGGL(rrt_init_kernel<0>, ig, dim3(256), 0, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
         hipLaunchKernelGGL(rrt_dubins_block_kernel, dim3((unsigned)b->Q), dim3(TPB), 0, ctx->stream, v);
         HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
@@ -992,7 +968,7 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
     const size_t lds_static = b->serial_lds_static - 1;
     if ((int)(lds + lds_static) > ctx->max_lds) return fail(ctx, RRT_E_HIP, "LDS request %zu exceeds %d", lds + lds_static, ctx->max_lds);
     HIPCHK(ctx, raise_dynamic_lds(ctx->device, reinterpret_cast<const void *>(kern), (int)lds));
-    hipLaunchKernelGGL(rrt_init_kernel, ig, dim3(256), 0, ctx->stream, v);
+    hipLaunchKernelGGL(rrt_init_kernel<0>, ig, dim3(256), 0, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev0, ctx->stream));
     hipLaunchKernelGGL(kern, dim3((unsigned)b->Q), dim3(TPB), lds, ctx->stream, v);
     HIPCHK(ctx, hipEventRecord(b->ev1, ctx->stream));
@@ -1063,7 +1039,6 @@ extern "C" int rrt_batch_kernel_name(rrt_batch *b, char *buf, int32_t len) {
         const int team = b->last_team > 0 ? b->last_team : b->team;
         const int bsm = b->last_wide ? 32 : (team <= 4 ? 16 : 64 / team);
         if (b->last_pipe1) snprintf(tmp, sizeof tmp, "rrt_pipe_kernel");
-        else if (b->split) snprintf(tmp, sizeof tmp, "rrt_block_work_kernel<%d, %d, false> + rrt_block_commit_kernel<%d, %d, false>", team, bsm, team, bsm);
         else snprintf(tmp, sizeof tmp, "rrt_expand_block_kernel<%d, %d, %s, %s>", team, bsm, (team > 1 && b->pipe) ? "true" : "false", b->last_inf ? "true" : "false");
     } else if (b->dub_block) {
         snprintf(tmp, sizeof tmp, "rrt_dubins_block_kernel");

@@ -359,8 +359,13 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
 // DUB = true: the Dubins planners (alg 3 Dubins-RRT, 4 Dubins-RRT*; no reference counterpart, include/rrt_dubins.h): every
 // node and sample carries a heading, an edge is the shortest Dubins word between the two poses, its cost the word's arc
 // length, its collision test the sampled sweep of the word; nearest / within / accept / choose-parent order are unchanged.
+// (RRT_SERIAL_DECL_ONLY: a translation unit that only launches the kernel; csrc/kernels_tu.hip instantiates it)
 template <bool RW, bool DUB = false>
-__global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
+__global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv)
+#ifdef RRT_SERIAL_DECL_ONLY
+    ;
+#else
+{
     static_assert(!(RW && DUB), "the opt-in rewire is not built for the Dubins planners");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // node cache: lds_chunks * 16 KiB
     __shared__ __attribute__((aligned(16))) u32x2 wlist_lds[NWAVE * WCAP];
@@ -1108,10 +1113,13 @@ __global__ __launch_bounds__(TPB) void rrt_expand_kernel(BatchView bv) {
 #endif
     }
 }
+#endif  // RRT_SERIAL_DECL_ONLY
 
 // Arms query state in HBM: clears the `sampled` bitmap, writes node 0 (rrt.py:411-413) and fills the unfilled
 // node slots with a copy of node 0 (the block kernel scans whole 4096-node steps; such a slot can never be the
 // nearest node -- equal distance, higher index -- and is dropped from near sets by its index).
+// (a template only so that every translation unit may see the definition: instantiated where it is launched)
+template <int = 0>
 __global__ void rrt_init_kernel(BatchView bv) {
     const int q = (int)blockIdx.y;
     const QDesc *D = bv.desc + q;

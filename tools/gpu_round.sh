@@ -2,7 +2,7 @@
 # One GPU-box session: the -m gpu suite, the bench lines and the rocprofv3 passes whose summaries go to profiles/.
 #   gpurun --timeout 1200 -- bash tools/gpu_round.sh [tests|bench|prof|pmc ...]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r03
+O=$R/gpurun_out/r04
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
@@ -84,6 +84,6 @@ pmc)
             echo "pmc c$c q$q $name rc=$?"
         done
     done
-    (cd $R && python3 tools/pmc_to_json.py $O "${SPECS[@]}" && cp profiles/r03_traffic.json profiles/r03_sq_counters.json $O/) ;;
+    (cd $R && python3 tools/pmc_to_json.py $O "${SPECS[@]}" && cp profiles/r04_traffic.json profiles/r04_sq_counters.json $O/) ;;
 esac
 done

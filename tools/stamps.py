@@ -18,12 +18,11 @@ ap.add_argument("--queries", type=int, default=1)
 ap.add_argument("--grid", type=int, default=1024)
 ap.add_argument("--team", type=int, default=None, help="CUs per query: 1, 2, 4 (default: as many as fit)")
 ap.add_argument("--serial", action="store_true")
-ap.add_argument("--split", action="store_true", help="RRT_FLAG_SPLIT_COMMIT: committer and workers as two kernels")
 a = ap.parse_args()
 og = perlin_occupancygrid(a.grid, a.grid, seed=1)
 free = np.argwhere(og == 0)
 ctx = _ffi.Context(0); ctx.set_grid(hostprep.og_nonzero(og))
-b = _ffi.Batch(ctx, a.queries, a.n, serial=a.serial, team=a.team, split=a.split)
+b = _ffi.Batch(ctx, a.queries, a.n, serial=a.serial, team=a.team)
 sg = np.random.default_rng(7); keep = []
 for q in range(a.queries):
     xs, xg = random_connected_pair(og, sg)
