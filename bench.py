@@ -57,6 +57,20 @@ def algorithmic_bytes(res):
     return 8 * res.sum_j + res.sum_cells_nn + 8 * res.sum_near + res.sum_cells_cand + 20 * (res.j - 1)
 
 
+def lib_build_id():
+    """sha256 (first 16 hex digits) of the HIP library this process loads: every bench line and every profile taken through
+    tools/gpu_round.sh carries it, so that a committed counter pass can be tied to the binary it measured."""
+    import hashlib
+
+    from rrtplanner_amd import _ffi
+
+    try:
+        with open(_ffi.LIB_PATH, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def committed_json(name):
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -69,12 +83,12 @@ def measured_traffic(config, Q, n, team, pipelined):
     """HBM bytes per launch of rrt_expand_block_kernel from the committed rocprofv3 PMC passes (profiles/*_traffic.json), only
     when a pass was taken on this exact workload AND kernel variant (team size, pipeline); None otherwise (the counters cannot
     be read from inside the bench)."""
-    for name in ("r03_traffic.json", "r02_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         t = committed_json(name)
         for e in (t or {}).get("entries", []):
             if (e.get("config"), e.get("queries_per_gpu"), e.get("n"), e.get("team"), e.get("pipelined")) == (config, Q, n, team, bool(pipelined)):
-                return e["hbm_bytes_per_launch"], "profiles/" + name
-    return None, None
+                return e["hbm_bytes_per_launch"], "profiles/" + name, e.get("build_sha256")
+    return None, None, None
 
 
 def roofline_block(config, Q, n, team, pipelined, kernel, kernel_ms, model_bytes, fallbacks):
@@ -89,18 +103,25 @@ def roofline_block(config, Q, n, team, pipelined, kernel, kernel_ms, model_bytes
     bound_observed: what the SQ counters of the same kernel say it waits on (profiles/r03_sq_counters.json)."""
     ach = model_bytes / (kernel_ms * 1e-3) / 1e9
     over = ach > HBM_PEAK_GBS
-    traffic, src = (None, None) if fallbacks else measured_traffic(config, Q, n, team, pipelined)
+    traffic, src, tbuild = (None, None, None) if fallbacks else measured_traffic(config, Q, n, team, pipelined)
+    build = lib_build_id()
+    if traffic is not None and tbuild != build:
+        # the counter pass measured another binary (or one of unknown identity): not this kernel's traffic
+        src = f"{src} was taken on build {tbuild}, this run is build {build}: not reported"
+        traffic = None
+    elif src:
+        src += f" (an earlier run of this workload and kernel variant on the same build {build}, not this run)"
     r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if over else ach / HBM_PEAK_GBS,
-         "model_exceeds_peak": over, "traffic": traffic, "traffic_source": (src + " (an earlier run of this workload and kernel variant, not this run)") if src else None,
+         "model_exceeds_peak": over, "traffic": traffic, "traffic_source": src, "traffic_build": tbuild,
          "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(model_bytes),
          "achieved_is": "SURVEY 8(d) algorithmic (model) bytes per second, not measured HBM traffic: see `measured`",
          "measured": None, "bound_observed": None}
     if traffic is not None:
         gbs = traffic / (kernel_ms * 1e-3) / 1e9
         r["measured"] = {"hbm_bytes": int(traffic), "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
-    sq = committed_json("r03_sq_counters.json") or committed_json("r02_sq_counters.json")
+    sq = committed_json("r04_sq_counters.json") or committed_json("r03_sq_counters.json") or committed_json("r02_sq_counters.json")
     for e in (sq or {}).get("entries", []):
-        if (e.get("config"), e.get("queries_per_gpu")) == (config, Q):
+        if (e.get("config"), e.get("queries_per_gpu")) == (config, Q) and e.get("build_sha256") == build:
             r["bound_observed"] = {"kind": e.get("kind", "latency"), "waves_waiting_frac": e.get("waves_waiting_frac"),
                                    "waves_issuing_frac": e.get("waves_issuing_frac"), "valu_busy_frac": e.get("valu_busy_frac"),
                                    "source": e.get("source")}
@@ -182,6 +203,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="2-4: BASELINE.json configs[1..3]; 5: configs[4] (Dubins-RRT*, no reference parity)")
     ap.add_argument("--queries", type=int, default=None, help="queries per GPU (default: the config's)")
+    ap.add_argument("--total-queries", type=int, default=None,
+                    help="the whole job (BASELINE.json configs[3]: 512 queries) divided over the ranks, total / N per GPU: strong scaling")
+    ap.add_argument("--no-plan-wall", action="store_true", help="skip the plan() wall-time leg (config 2, one GPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path on a one-GPU box: every rank on device 0 (needs RRT_RCCL_LIB = a stand-in collective "
+                         "library such as tests/fake_rccl, RCCL refuses two ranks on one device); the line says so, it is no scaling measurement")
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--team", type=int, default=None, choices=[1, 2, 3, 4, 8, 16, 32, 64],
                     help="cap on the CUs per query (default: the largest team for which all teams are resident together)")
@@ -215,6 +242,10 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.queries:
         cfg["queries"] = args.queries
+    if args.total_queries:
+        if args.total_queries % world:
+            raise SystemExit(f"--total-queries {args.total_queries} does not divide over {world} ranks")
+        cfg["queries"] = args.total_queries // world
     if args.n:
         cfg["n"] = args.n
     Q, n, alg = cfg["queries"], cfg["n"], cfg["alg"]
@@ -228,7 +259,9 @@ def main():
     r2 = hostprep.radius_threshold(cfg["r_rewire"])
     gd2 = hostprep.goal_threshold(cfg["r_goal"]) if cfg["r_goal"] is not None else 0
 
-    ctx = _ffi.Context(local_rank)
+    if args.share_gpu and not os.environ.get("RRT_RCCL_LIB"):
+        raise SystemExit("--share-gpu needs RRT_RCCL_LIB (a stand-in collective library, e.g. tests/fake_rccl/libfake_rccl.so)")
+    ctx = _ffi.Context(0 if args.share_gpu else local_rank)
     if use_comm:
         multi.init_comm(ctx, rank, world)  # RCCL communicator (ncclCommInitRank), id handed over on local tmpfs
     ctx.set_grid(og8)
@@ -346,15 +379,18 @@ def main():
             # descriptor read-back and the host's wait (for N > 1 also the gather and its sync)
             "host_gap_ms": ms_per_step - kern_avg_ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_queries else "weak",
             "vs_baseline": None,
             "dtype": "int16x2 coordinates / u32 squared distances / f64 costs",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {cfg['name']}", "queries_per_gpu": Q, "n": n,
+            "build": {"lib_sha256": lib_build_id(), "lib": os.path.basename(_ffi.LIB_PATH)},
+            "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {cfg['name']}" + (f" -- the whole job of {args.total_queries} queries over {world} GPU(s)" if args.total_queries else ""),
+                       "queries_per_gpu": Q, "total_queries": Q * world, "n": n,
                        "grid": [cfg["grid"], cfg["grid"]], "free_fraction": float((og == 0).mean()),
                        "iters_per_s": iters_total * args.steps / dt, "unfinished_queries": nbad,
                        "cus_per_query": team + (1 if pipelined else 0), "pipelined": pipelined,
-                       "team_fallbacks": fallbacks, "collective": "rrt_gather (ncclAllGather, C ABI)" if use_comm else None},
+                       "team_fallbacks": fallbacks, "collective": "rrt_gather (ncclAllGather, C ABI)" if use_comm else None,
+                       "rehearsal_shared_gpu": bool(args.share_gpu), "collective_library": os.environ.get("RRT_RCCL_LIB") or "librccl.so.1"},
             "roofline": roofline_block(args.config, Q, n, team, pipelined, batch.kernel_name(), kern_avg_ms, bytes_local, fallbacks),
         }
         if dubins:
@@ -381,6 +417,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(og8, cfg, pairs[0], free, states[0], ub_cache.get(0), results[0])
         if world == 1 and args.config == 2 and not args.no_batched:
             out["batched"] = batched_leg(ctx, og, og8, free, _ffi, hostprep)
+        if world == 1 and args.config == 2 and not args.no_plan_wall and not args.queries and not args.n and not args.team and not args.serial:
+            out["plan_wall"] = plan_wall_leg(og, cfg, pairs[0])
         if world == 1 and args.rewire_leg and alg >= 1:
             out["rewire_correct"] = rewire_leg(ctx, og8, cfg, pairs[0], free, states[0], _ffi, hostprep)
         sys.stdout.flush()
@@ -391,6 +429,40 @@ def main():
         ctx.barrier()
     batch.close()
     ctx.close()
+
+
+def plan_wall_leg(og, cfg, pair):
+    """Informational: the reference's own unit of work (SURVEY.md 8(d) metric: n / wall time of plan(), rrt.py:466-556) through the
+    planner class -- sample draw on the host, upload, expansion kernel, read-back, the lazy graph object -- and what the reference's
+    consumers then do with the graph (plots.py:27-29 walks every edge): the first and a second walk over `T.edges(data=True)`."""
+    from rrtplanner_amd import RRTStar
+
+    xs, xg = pair
+    p = RRTStar(og, cfg["n"], cfg["r_rewire"], pbar=False, seed=0)
+    p.plan(xs, xg)  # context, grid upload, first launch
+    ts, T, nodes = [], None, 0
+    for _ in range(7):
+        t0 = time.perf_counter()
+        T, gv = p.plan(xs, xg)
+        ts.append((time.perf_counter() - t0) * 1e3)
+        nodes = p.last_stats["j"] - 1
+    ts.sort()
+    t0 = time.perf_counter()
+    k = 0
+    for u, v, d in T.edges(data=True):
+        k += 1
+    t1 = time.perf_counter()
+    for u, v, d in T.edges(data=True):
+        k += 1
+    t2 = time.perf_counter()
+    still_arrays = T.lazy_points() is not None
+    if p._ctx is not None:
+        p._ctx.close()
+    return {"what": "RRTStar(og, n=50000, r_rewire=64).plan(xstart, xgoal) wall time: sample draw + upload + kernel + read-back + graph object (7 calls after a warm-up, "
+                    "each with the generator's next samples)",
+            "ms": ts[len(ts) // 2], "ms_min": ts[0], "ms_max": ts[-1], "nodes_per_s": nodes / (ts[len(ts) // 2] * 1e-3),
+            "edges_iter_ms": (t1 - t0) * 1e3, "edges_iter_again_ms": (t2 - t1) * 1e3, "edges": k // 2,
+            "graph_still_array_backed_after_the_walks": still_arrays}
 
 
 def batched_leg(ctx, og, og8, free, _ffi, hostprep):

@@ -177,6 +177,11 @@ int rrt_batch_result_block(rrt_batch *b, void **dev_ptr, int64_t *bytes);
  * slabs over RCCL / xGMI at the end of a batch.  The reference has no counterpart (single process).
  * librccl is opened on the first of these calls; the single-GPU path never loads it. ---- */
 #define RRT_COMM_ID_BYTES 128
+/* Optional, before the first rrt_comm_* call of the process: the collective library to open instead of librccl.so.1 -- any library
+ * that exports ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclAllReduce / ncclGetErrorString with RCCL's
+ * signatures.  tests/fake_rccl is one for ranks that share ONE GPU (RCCL itself refuses two ranks on a device), so that the
+ * world > 1 path can run on a one-GPU box.  RRT_E_COMM once a library has been opened; path NULL = back to the default. */
+int rrt_comm_use_library(const char *path);
 /* rank 0: a fresh communicator id (ncclGetUniqueId); the host ships the bytes to the other ranks over any side channel */
 int rrt_comm_unique_id(uint8_t id[RRT_COMM_ID_BYTES]);
 /* collective over all `world` ranks (ncclCommInitRank on the context's device) */
@@ -184,9 +189,11 @@ int rrt_comm_init(rrt_ctx *ctx, int32_t rank, int32_t world, const uint8_t id[RR
 int rrt_comm_destroy(rrt_ctx *ctx);
 /* vals[0..count) := reduction over all ranks (op 0 sum, 1 max, 2 min), count <= 64; synchronous: also the barrier */
 int rrt_comm_allreduce_f64(rrt_ctx *ctx, double *vals, int32_t count, int32_t op);
-/* ncclAllGather of the batch's result slab on the context's stream (asynchronous): rank r's slab lands at
- * gathered_dev + r * bytes_per_rank on every rank.  Every rank must bring a batch of the same Q and capacity: checked by a
- * 16-byte all-reduce in front of every gather (RRT_E_COMM on all ranks when the sizes differ). */
+/* ncclAllGather of the batch's result slab on the context's stream: rank r's slab lands at gathered_dev + r * bytes_per_rank on
+ * every rank.  Every rank must bring a batch of the same Q and capacity: checked by a 16-byte all-reduce in front of EVERY gather
+ * (RRT_E_COMM on all ranks when the sizes differ).  That check is host-synchronous (it is rrt_comm_allreduce_f64: also a barrier
+ * of the ranks), so the call returns after all ranks have entered it; only the all-gather itself is left asynchronous on the
+ * stream (rrt_ctx_sync / the next synchronous call waits for it). */
 int rrt_gather(rrt_batch *b, void **gathered_dev, int64_t *bytes_per_rank);
 /* after rrt_gather ON THIS BATCH (the slabs of another batch, even one of equal size, are refused): query q of rank `rank` from
  * the gathered slabs into caller-allocated host arrays.  On entry out->rows is the CAPACITY of pts / vcost / parent in rows (the

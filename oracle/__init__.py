@@ -243,3 +243,65 @@ def dubins_plan(og8, n, star, xs, xg, samples, headings, r2_rewire=0, rho=8.0, n
               "near_of_rejected", "lb_static_skip", "lb_evals", "lb_sweeps", "lb_violations", "lb_mismatch"):
         setattr(r, k, getattr(p, k))
     return status, r
+
+
+# ---------------------------------------------------------------------------------- independent Dubins check (oracle/dubins_ref.c)
+_DUBREF_SO = os.path.join(_HERE, "libdubref.so")
+_dubref = None
+
+
+class _DubAudit(C.Structure):
+    _fields_ = [
+        ("star", C.c_int32), ("n", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+        ("og", C.c_void_p), ("r2_rewire", C.c_int64), ("rho", C.c_double), ("nh", C.c_int32), ("pad_", C.c_int32),
+        ("samples", C.c_void_p), ("headings", C.c_void_p),
+        ("pts", C.c_void_p), ("head", C.c_void_p), ("vcost", C.c_void_p), ("parent", C.c_void_p),
+        ("j", C.c_int32), ("pad2_", C.c_int32),
+        ("n_accepted", C.c_int64), ("accept_mismatch", C.c_int64), ("accept_ambiguous", C.c_int64), ("nearest_mismatch", C.c_int64),
+        ("parent_is_argmin", C.c_int64), ("parent_within_tol", C.c_int64), ("parent_wrong", C.c_int64), ("parent_blocked", C.c_int64),
+        ("parent_blocked_ambiguous", C.c_int64), ("cost_mismatch", C.c_int64), ("max_cost_err", C.c_double),
+        ("words", C.c_int64), ("sweeps", C.c_int64), ("first_bad_iter", C.c_int64),
+    ]
+
+
+def dubref_lib():
+    """libdubref.so: textbook Dubins words on libm with their own sweep; does NOT include include/rrt_dubins.h."""
+    global _dubref
+    if _dubref is None:
+        src = os.path.join(_HERE, "dubins_ref.c")
+        if not os.path.exists(_DUBREF_SO) or os.path.getmtime(_DUBREF_SO) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", "libdubref.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(_DUBREF_SO)
+        L.dubref_audit.argtypes = [C.POINTER(_DubAudit)]
+        L.dubref_audit.restype = C.c_int
+        L.dubref_shortest.argtypes = [C.c_double] * 7 + [C.c_void_p]
+        L.dubref_shortest.restype = None
+        _dubref = L
+    return _dubref
+
+
+def dubref_shortest(x0, y0, th0, x1, y1, th1, rho):
+    out = np.zeros(5)
+    dubref_lib().dubref_shortest(float(x0), float(y0), float(th0), float(x1), float(y1), float(th1), float(rho), out.ctypes.data)
+    return out[0], out[1], out[2], out[3], int(out[4])
+
+
+def dubins_audit(og8, n, star, samples, headings, pts, head, vcost, parent, j, r2_rewire=0, rho=8.0, nh=64):
+    """Recompute every decision behind the tree (pts, head, vcost, parent; j vertices) with dubins_ref.c's own arithmetic and count
+    where they differ (see that file's head comment).  Returns a dict of the counters."""
+    og8 = np.ascontiguousarray(og8, dtype=np.uint8)
+    samples = np.ascontiguousarray(samples, dtype=np.int32)
+    headings = np.ascontiguousarray(headings, dtype=np.int32)
+    pts = np.ascontiguousarray(pts, dtype=np.int32)
+    head = np.ascontiguousarray(head, dtype=np.int32)
+    vcost = np.ascontiguousarray(vcost, dtype=np.float64)
+    parent = np.ascontiguousarray(parent, dtype=np.int32)
+    a = _DubAudit()
+    a.star, a.n, a.W, a.H = int(bool(star)), int(n), og8.shape[0], og8.shape[1]
+    a.og, a.r2_rewire, a.rho, a.nh = og8.ctypes.data, int(r2_rewire), float(rho), int(nh)
+    a.samples, a.headings = samples.ctypes.data, headings.ctypes.data
+    a.pts, a.head, a.vcost, a.parent, a.j = pts.ctypes.data, head.ctypes.data, vcost.ctypes.data, parent.ctypes.data, int(j)
+    rc = dubref_lib().dubref_audit(C.byref(a))
+    if rc != 0:
+        raise ValueError("dubref_audit: bad argument")
+    return {k: getattr(a, k) for k, _ in _DubAudit._fields_[17:]}

@@ -54,7 +54,7 @@ def kernel_flags(logs=False, serial=False, team=None, team_fault=False, pipe=Tru
 SYMBOLS = (
     "rrt_ctx_create", "rrt_ctx_destroy", "rrt_last_error_string", "rrt_set_grid", "rrt_noise_grids", "rrt_select_frame",
     "rrt_grid_generation", "rrt_ctx_sync",
-    "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_comm_allreduce_f64", "rrt_gather", "rrt_gather_fetch",
+    "rrt_comm_use_library", "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_comm_allreduce_f64", "rrt_gather", "rrt_gather_fetch",
     "rrt_batch_create", "rrt_batch_destroy", "rrt_batch_set_query", "rrt_batch_set_unitball",
     "rrt_batch_rearm", "rrt_batch_launch", "rrt_batch_sync", "rrt_batch_team", "rrt_batch_team_info", "rrt_batch_pipelined", "rrt_batch_kernel_name", "rrt_batch_elapsed_ms",
     "rrt_batch_get_result", "rrt_batch_result_block", "rrt_batch_debug_cycles",
@@ -118,6 +118,7 @@ def lib():
             "rrt_select_frame": ([vp, i32], C.c_int),
             "rrt_grid_generation": ([vp, C.POINTER(C.c_uint64)], C.c_int),
             "rrt_ctx_sync": ([vp], C.c_int),
+            "rrt_comm_use_library": ([C.c_char_p], C.c_int),
             "rrt_comm_unique_id": ([vp], C.c_int),
             "rrt_comm_init": ([vp, i32, i32, vp], C.c_int),
             "rrt_comm_destroy": ([vp], C.c_int),
@@ -169,6 +170,12 @@ def _check(ctx_handle, rc, ok=(RRT_OK,)):
 
 
 COMM_ID_BYTES = 128
+
+
+def comm_use_library(path):
+    """Before the first communicator of the process: open `path` instead of librccl.so.1 (None: the default).  For ranks that
+    share one GPU (tests/fake_rccl); see include/rrt_hip.h."""
+    _check(None, lib().rrt_comm_use_library(None if path is None else os.fsencode(path)))
 
 
 def comm_unique_id() -> bytes:

@@ -63,7 +63,13 @@ constexpr int TEAM_MAX = 64;
 #define RRT_NPMAX 2  // most blocks in flight a record can carry interaction masks for (>= both RRT_PIPE_LAG values)
 #endif
 constexpr int NPMAX = RRT_NPMAX;
-constexpr int BREC_WORDS = 10 + 3 * NPMAX;       // 8-byte words of an owner's record (BRec below): 128 bytes for two blocks in flight
+// Owners on big teams (a group of waves per sample) also test the lines of sight from every sample IN FLIGHT within r_rewire to
+// their sample -- positions come from the sample stream, not from the tree -- and hand the answers over as a list of up to PL_MAX
+// 16-bit entries, so that the committer settles "an inserted sample in flight is a cheaper parent" (nine in ten of the samples a
+// commit has to look at again) lane-parallel, without a line-of-sight test of its own.  Entry: bits 0-5 sample, 6-7 set (0 = oldest
+// previous block ... NP = this block), 8-14 cells the test read, 15 free; order: oldest block first, sample order = node order.
+constexpr int PL_MAX = 12, PL_WORDS = 3;
+constexpr int BREC_WORDS = 10 + 3 * NPMAX + PL_WORDS;  // 8-byte words of an owner's record (BRec below): 152 bytes for two blocks in flight
 // per query: [go | fail | state (NPMAX + 1 slots of 64 bytes) | records (NPMAX + 1 slots of 64) | arrival flags (65 x 128) | go2goal answers (65 x 16)]
 constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384, TEAM_OFF_REC = 1024;
 constexpr int TEAM_OFF_ARRIVE = (TEAM_OFF_REC + (NPMAX + 1) * 64 * BREC_WORDS * 8 + 127) / 128 * 128;
@@ -108,6 +114,20 @@ __device__ __forceinline__ u32x4 ld_rec(const u32x4 *p) {  // (two 8-byte halves
         return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
     }
     return *p;
+}
+
+// 16 bytes at agent scope (what the compiler emits for an agent-scope atomic load, at four times the width the atomic builtins
+// reach).  The caller issues all its loads, then fence_b128s(), then uses the values.
+__device__ __forceinline__ u32x4 ld_b128_agent(const void *p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void fence_b128s(u32x4 (&v)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));  // (every use of v[k] stays behind the wait)
 }
 
 // A value every lane of the wave holds alike (read from LDS or memory): moved to scalar registers, so that it does not
@@ -176,7 +196,8 @@ __device__ __forceinline__ uint32_t key16(uint32_t node_s, uint32_t q_s, uint32_
 struct BRec {
     uint32_t d2s, vs;   // snapshot nearest
     uint32_t los_s;     // line of sight vs -> sample: bit 31 free, low bits cells read
-    uint32_t flags;     // bit 0: cell already in `sampled` at the snapshot; bit 1 (committer's copy): re-resolved, nnear counts the block's nodes
+    uint32_t flags;     // bit 0: cell already in `sampled` at the snapshot; bit 1 (committer's copy): re-resolved, nnear counts the block's nodes;
+                        // bits 8-15: samples in flight within r_rewire (0 where no list is kept; more than PL_MAX: the list is void)
     double Vs;          // vcost[vs]
     double cbest;       // cost of the sample through its snapshot-resolved parent
     uint32_t vbest;     // snapshot-resolved parent (vs, or the best passing near-set entry)
@@ -189,6 +210,7 @@ struct BRec {
     u64 dupmask;        // earlier samples on the same cell
     u64 pnn[NPMAX], pr[NPMAX], pdup[NPMAX];  // pipelined teams: the same three masks against the samples of the previous super-block [0]
                                  // and of the one before it [1] (workers two blocks ahead of the commit)
+    u64 plist[PL_WORDS];         // big pipelined teams: lines of sight from the samples in flight within r_rewire (see PL_MAX)
 };
 static_assert(sizeof(BRec) == 8 * BREC_WORDS, "BRec size");
 union BRecWords {
@@ -257,8 +279,8 @@ struct BlockLds {
     static constexpr int SB = BSM * G, NP = PipeShape<PIPE, INF>::NP;
     alignas(16) u32x2 nnx[(BSM <= BS ? BSM : 1) * NWAVE];     // per own sample, per wave: {d2, idx} (phase A; not with more than 16 samples per member)
     alignas(16) BRec brec[PIPE ? 2 : 1][SB];  // (a pipelined committer: this block's records and the next one's)
-    uint32_t xq_next[PIPE ? 64 : 1];        // pipelined committer: the next block's samples and whether its records are in
-    uint32_t pre_state;
+    uint32_t xq_next[PIPE ? 2 : 1][PIPE ? 64 : 1];  // pipelined committer: the next block's samples and whether its records are in,
+    uint32_t pre_state[2];                          // by the half of brec they belong to (fetched while the block before them commits)
     alignas(16) BSlot bslots[2 * NWAVE];
     alignas(16) BlkState blk;
     alignas(16) unsigned long long statred[SB * 5];
@@ -273,6 +295,8 @@ struct BlockLds {
     uint32_t slots[BSM >= 16 ? NWAVE : 1][64];  // single-wave owners: the cell starts of a step of the near-set stream
     alignas(16) GSlot gslot[NWAVE];
     alignas(16) GCtl gctl[BSM];
+    alignas(8) uint16_t plist[(PIPE && BSM < 16) ? BSM : 1][PL_MAX];  // a group's list of in-flight lines of sight, filled by its waves
+    uint32_t oq_cnt[(PIPE && BSM < 16) ? BSM : 1], oq_ovf;  // worker groups: fill of a blocked sample's queue of open candidates, "a queue overflowed"
 #ifdef RRT_STAMPS
     unsigned long long dbg[16];  // pipelined teams: phase cycles of wave 0 of the committer and of worker 1
 #endif
@@ -333,6 +357,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     auto &gslot = L.gslot;
     auto &gctl = L.gctl;
     constexpr int WPS = BSM >= 16 ? 1 : NWAVE / BSM;  // waves per sample in the owner phase
+    constexpr bool FASTL = PIPE && WPS > 1;  // records carry the lines of sight from the samples in flight (PL_MAX): big pipelined teams
     const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
     int q = (int)blockIdx.x, g_ = 0;  // query, team member
     if (G > 1) {
@@ -344,7 +369,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     const int g = ROLE == ROLE_COMMIT ? 0 : g_;
     if (ROLE == ROLE_WORK) __builtin_assume(g > 0);
     const bool worker = !PIPE || ROLE == ROLE_WORK;  // scans and resolves samples (a pipelined team's member 0 only commits)
-    const int wg = PIPE ? g - 1 : g;     // which BSM samples of a super-block this workgroup owns
+    const int wg = PIPE ? (ROLE == ROLE_COMMIT ? 0 : g - 1) : g;  // which BSM samples of a super-block this workgroup owns (a committer: none)
     QDesc *D = bv.desc + q;
     if (D->status != ST_RUNNING) return;
     unsigned char *tb = (G > 1) ? bv.team + (size_t)q * TEAM_BYTES : nullptr;
@@ -422,18 +447,40 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     auto &dbg = L.dbg;
     if (t < 16) dbg[t] = 0;
     unsigned long long dbgt = __builtin_amdgcn_s_memtime();
+#ifdef RRT_STAMPS_LIGHT  // only the stamps named by this bit mask (a stamp costs ~200 cycles: sixteen per block shift the balance of the ring)
+#define DBGT(k)                                                      \
+    do {                                                             \
+        if (((RRT_STAMPS_LIGHT) >> (k)) & 1) {                       \
+            unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+            if (t == 0) dbg[k] += now_ - dbgt;                       \
+            dbgt = now_;                                             \
+        }                                                            \
+    } while (0)
+#else
 #define DBGT(k)                                                  \
     do {                                                         \
         unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
         if (t == 0) dbg[k] += now_ - dbgt;                       \
         dbgt = now_;                                             \
     } while (0)
+#endif
 #else
 #define DBGT(k) \
     do {        \
     } while (0)
 #endif
 
+#if defined(RRT_STAMPS)
+    // wall-clock stamp of event ev of block ep (blocks 300 .. 331 of query 0's run), by one lane
+#define TSMARK(ep, ev)                                                                                          \
+    do {                                                                                                        \
+        if ((int)(ep) >= 300 && (int)(ep) < 332 && lane == 0) D->ts[((int)(ep) - 300) * 16 + (ev)] = wall_clock64(); \
+    } while (0)
+#else
+#define TSMARK(ep, ev) \
+    do {               \
+    } while (0)
+#endif
 #if defined(RRT_STAMPS) && defined(RRT_STAMPS_OWNER)
     unsigned long long wst_ = 0;
 #define WST0() (wst_ = __builtin_amdgcn_s_memtime())
@@ -466,6 +513,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         if (t < SB * 5) statred[t] = 0;
         if (t < NWAVE) L.help_n[t] = 0;
         if (t == 0) L.help_any = 0;
+        if (t < (int)(sizeof(L.oq_cnt) / sizeof(uint32_t))) L.oq_cnt[t] = 0;
+        if (t == 0) L.oq_ovf = 0;
     }
     __syncthreads();
 
@@ -488,32 +537,40 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // Where one wave resolves a sample (BSM == 16) the first 256 entries of its list live in LDS, the rest in HBM: a sample whose
     // two cheapest candidates are blocked reads its list back several times, and that sample is the one its whole block waits
     // for.  Groups of waves (each with a share of the ball) keep their lists in HBM.
-    constexpr bool LDSLIST = BSM >= 16;
+    // GQ: the workers of a big pipelined team (a group of waves per sample).  A sample whose two cheapest candidates are blocked puts its
+    // open candidates into ONE queue per group, in the half of brec only a committer uses, and all the group's waves test them eight
+    // per wave and memory round trip (see the owner phase).  (Round 4 also kept the waves' parked lists there: no gain, dropped.)
+    constexpr bool GQ = PIPE && ROLE == ROLE_WORK && BSM < 16;
+    constexpr uint32_t OQCAP = (uint32_t)(SB * BREC_WORDS * 8 / 16 / (BSM < 16 ? BSM : 1));
+    constexpr bool GLIST = false;
+    constexpr bool LDSLIST = BSM >= 16 || GLIST;
+    constexpr uint32_t LCAP = BSM >= 16 ? (uint32_t)BLOCK_LIST_CAP : (uint32_t)(SB * BREC_WORDS * 8 / 16 / NWAVE);
     const uint32_t clist_cap = (uint32_t)(bv.spill_stride / (2 * NWAVE * (G + (PIPE ? 1 : 0))));  // the engine sizes the spill area per team member
     u32x4 *const clist_base = reinterpret_cast<u32x4 *>(spill) + (size_t)(g * NWAVE) * (size_t)clist_cap;  // this member's 16 lists (and go2goal's scratch)
     u32x4 *const clist = clist_base + (size_t)wave * (size_t)clist_cap;
     RRT_LDS u32x4 *const clist_l =
-        (RRT_LDS u32x4 *)(smem + (size_t)lds_chunks * CHUNK * sizeof(uint32_t) + (size_t)MAX_CELLS * sizeof(uint32_t)) + (size_t)wave * BLOCK_LIST_CAP;
+        GLIST ? (RRT_LDS u32x4 *)&brec[PIPE ? 1 : 0][0] + (size_t)wave * LCAP
+              : (RRT_LDS u32x4 *)(smem + (size_t)lds_chunks * CHUNK * sizeof(uint32_t) + (size_t)MAX_CELLS * sizeof(uint32_t)) + (size_t)wave * LCAP;
     auto lget = [&](uint32_t p) -> u32x4 {
-        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) return clist_l[p];
+        if (LDSLIST && p < LCAP) return clist_l[p];
         return clist[p];
     };
     auto lput = [&](uint32_t p, u32x4 e) {
-        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) clist_l[p] = e;
+        if (LDSLIST && p < LCAP) clist_l[p] = e;
         else clist[p] = e;
     };
     auto lput_y = [&](uint32_t p, uint32_t y) {
-        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) clist_l[p].y = y;
+        if (LDSLIST && p < LCAP) clist_l[p].y = y;
         else clist[p].y = y;
     };
     // the list of another wave of this workgroup (the cooperative test of a blocked sample's candidates)
-    RRT_LDS u32x4 *const clist_l0 = clist_l - (size_t)wave * BLOCK_LIST_CAP;  // wave 0's
+    RRT_LDS u32x4 *const clist_l0 = clist_l - (size_t)wave * LCAP;  // wave 0's
     auto lget_w = [&](int w, uint32_t p) -> u32x4 {
-        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) return clist_l0[(size_t)w * BLOCK_LIST_CAP + p];
+        if (LDSLIST && p < LCAP) return clist_l0[(size_t)w * LCAP + p];
         return (clist_base + (size_t)w * (size_t)clist_cap)[p];
     };
     auto lput_y_w = [&](int w, uint32_t p, uint32_t y) {
-        if (LDSLIST && p < (uint32_t)BLOCK_LIST_CAP) clist_l0[(size_t)w * BLOCK_LIST_CAP + p].y = y;
+        if (LDSLIST && p < LCAP) clist_l0[(size_t)w * LCAP + p].y = y;
         else (clist_base + (size_t)w * (size_t)clist_cap)[p].y = y;
     };
     // single-precision screen: vcost + sqrt(d2) evaluated in f32 is within a few f32 ulps (< 4e-7 relative) of the f64 value
@@ -555,7 +612,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (pm == 0) return;
             if (park) {
                 const uint32_t pos = nlist + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                if (pos < clist_cap) lput(pos, u32x4{rc.y, d2, rc.z, rc.w});
+                if (pos < clist_cap) lput(pos, u32x4{rc.y, rc.x, rc.z, rc.w});  // {index, xy, vcost}: whoever tests the entry has its coordinates at hand
             }
             nlist += (uint32_t)__builtin_popcountll(pm);
             // screens, cheapest first; none rejects an entry that belongs to the two cheapest
@@ -675,21 +732,22 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // every open entry is tested, one line of sight per LANE.
     // (wc, wi) = the cheapest passing entry; every entry with a key up to it has been tested and holds its cell count.
     // amin: a single-precision lower bound of the cheapest parked entry that is NOT below the bound (+inf: none).
-    auto consume_price = [&](double bound, double lbc, uint32_t lbi, uint32_t nlist, uint32_t &nval, float &amin) {
+    auto consume_price = [&](uint32_t X, double bound, double lbc, uint32_t lbi, uint32_t nlist, uint32_t &nval, float &amin) {
         const float boundf = screen_of(bound);
         nval = 0;
         float am = FINF;
         for (uint32_t p0 = 0; p0 < nlist; p0 += 64) {
             const uint32_t p = p0 + (uint32_t)lane;
             u32x4 e = {NONE, 0u, 0u, 0u};
-            if (p < nlist) e = lget(p);  // {index, d2, vcost}
+            if (p < nlist) e = lget(p);  // {index, xy, vcost}
             const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+            const uint32_t ed2 = dist2(e.y, X);
             double cn = f64_inf();
             if (p < nlist) {
-                const float cf = (float)V + __builtin_amdgcn_sqrtf((float)e.y);
+                const float cf = (float)V + __builtin_amdgcn_sqrtf((float)ed2);
                 bool below = false;  // certainly below the bound (such an entry is open, or one of the tested ones under the lower bound)
                 if (cf < boundf) {
-                    const double c = V + sqrt_u24(e.y);
+                    const double c = V + sqrt_u24(ed2);
                     below = c < bound;
                     if (below && !key_lt(c, e.x, lbc, lbi)) cn = c;
                 }
@@ -699,7 +757,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const unsigned long long om = __ballot(open);
             if (open) {  // positions at or below the ones this iteration has read
                 const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
-                lput(nval + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull)), u32x4{e.x, 0u, (uint32_t)cb, (uint32_t)(cb >> 32)});
+                // {index, xy, cost}: the test of an entry reads its coordinates from the second word and leaves the cells it read there
+                lput(nval + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull)), u32x4{e.x, e.y, (uint32_t)cb, (uint32_t)(cb >> 32)});
             }
             nval += (uint32_t)__builtin_popcountll(om);
         }
@@ -726,7 +785,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 const uint32_t pq = b0 + (uint32_t)(lane & 3);
                 u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
                 if (pq < nval) e = lget(pq);
-                const uint32_t axy = pq < nval ? node_xy(e.x) : X;
+                const uint32_t axy = pq < nval ? e.y : X;
                 uint32_t a4[4];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) a4[q4] = (uint32_t)__builtin_amdgcn_readlane((int)axy, q4);
@@ -769,7 +828,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             const bool have = p < nval;
             u32x4 e = {NONE, 0u, 0u, 0x7ff00000u};
             if (have) e = lget(p);
-            const uint32_t axy = have ? node_xy(e.x) : X;
+            const uint32_t axy = have ? e.y : X;
             const rrt_line_t ln = rrt_line_setup(ux(axy), uy(axy), ux(X), uy(X));
             const int L = ln.major;
             constexpr int WU = 16, NOHIT = 0x7fffffff;
@@ -817,9 +876,35 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         }
     };
 
+    // One line of sight PER LANE (a -> X for the lanes that `have` one), 16 cell loads in flight per lane and pass: the walk consume_walk
+    // makes over a long list, for entries a caller holds in its lanes.  cells as in los_wave.
+    auto los_per_lane = [&](bool have, uint32_t axy, uint32_t X, bool &blocked, int &cells) {
+        const rrt_line_t ln = rrt_line_setup(ux(have ? axy : X), uy(have ? axy : X), ux(X), uy(X));
+        const int L = ln.major;
+        constexpr int WU = 16, NOHIT = 0x7fffffff;
+        int fb = NOHIT;
+        for (int it = 0;; ++it) {
+            if (!__any(have && fb == NOHIT && it * WU <= L)) break;
+            const int k0 = it * WU;
+            uint8_t v[WU];
+#pragma unroll
+            for (int u = 0; u < WU; ++u) {
+                const int kk = (k0 + u) < L ? (k0 + u) : L;
+                int x, y;
+                rrt_line_cell(&ln, kk, &x, &y);
+                v[u] = og[(uint32_t)(x * H + y)];
+            }
+#pragma unroll
+            for (int u = 0; u < WU; ++u)
+                if (fb == NOHIT && k0 + u <= L && v[u] != 0) fb = k0 + u;
+        }
+        blocked = fb != NOHIT;
+        cells = blocked ? fb + 1 : L + 1;
+    };
+
     auto consume_list = [&](uint32_t X, double bound, double lbc, uint32_t lbi, uint32_t nlist, double &wc, uint32_t &wi, uint32_t &nval,
                             float &amin) {
-        consume_price(bound, lbc, lbi, nlist, nval, amin);
+        consume_price(X, bound, lbc, lbi, nlist, nval, amin);
         consume_walk(X, nval, wc, wi);
     };
 
@@ -927,9 +1012,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             return;
         }
         amin = 0.0f;  // both are below the bound: unknown unless the parked list tells
-#ifdef RRT_EXP_NOCONSUME
-        return;  // timing experiment only (wrong trees): what the blocked-candidate path of single-wave owners costs
-#endif
         if (nlist > clist_cap) {  // the list overflowed: stream again, bounded, above the two that are blocked
             uint32_t nn2 = 0;
             snapshot_parent(X, j0, false, bound, pc, pi, nn2, ntests, tcells, tt.c2, tt.i2 + 1);
@@ -937,7 +1019,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         }
         uint32_t nval = 0;
         if (defer) {
-            consume_price(bound, tt.c2, tt.i2 + 1, nlist, nval, amin);
+            consume_price(X, bound, tt.c2, tt.i2 + 1, nlist, nval, amin);
             open = nval;
             return;
         }
@@ -972,9 +1054,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // steps [c0, c1) of the scan: 4096 nodes per step, from the LDS cache or (beyond it) from HBM, next step prefetched
     const uint32_t node0 = xs;  // node 0 = the start
     auto scan_steps = [&](int c0, int c1, int jlim, const uint32_t (&xs16)[BSA], uint32_t (&best)[BSA]) {
-#ifdef RRT_EXP_SCAN1
-        c1 = c1 > 1 ? 1 : c1;  // timing experiment only (wrong trees): what the run costs without the brute-force scan
-#endif
         const int nl = c1 < lds_chunks ? c1 : lds_chunks;
         if (c0 < nl) {
             u32x4 cur = nodes_lds4[c0 * TPB + t];
@@ -1029,9 +1108,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #pragma unroll
             for (int w = 0; w < 5; ++w) __hip_atomic_store(t_state + (size_t)(ep % NSLOT) * 8 + w, u.w[w], RRT_RLX_AGENT);
         }
-#ifdef RRT_EXP_RELEASE
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // (the old form: plain stores + an L2 write-back)
-#endif
         // wave 0 made every store of the commit, all of them write-through (nodes, costs, parents, cell records, the bitmap's
         // atomic, the logs' plain stores are host-read only): the flag only must not overtake them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1086,6 +1162,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             continue;
         }
         if (ROLE == ROLE_COMMIT) DBGT(0);
+        if (ROLE == ROLE_COMMIT && wave == 0) TSMARK(epoch, 0);
         uint32_t xv = 0;  // lane s < nb: sample s
         if (lane < nb) {
             if (ell) {
@@ -1102,11 +1179,16 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 vy = (vy > 0.0) ? vy : 0.0;
                 xv = pack_xy((int)vx, (int)vy);
             } else {
-                if (PIPE && prefetched_smp) xv = xq_next[lane];  // (a branch of its own: merged with the global load it becomes a flat load)
+                if (PIPE && prefetched_smp) xv = xq_next[bsel][lane];  // (a branch of its own: merged with the global load it becomes a flat load)
                 else xv = (G > 1 && pre_i == i0) ? pre_xv : at32(samples, (uint32_t)(i0 + lane));
             }
         }
         if (!worker && t < SB) xq_lds[t] = xv;  // a pipelined team's committer: nothing to resolve
+#ifdef RRT_STAMPS
+        const unsigned long long wres0 = __builtin_amdgcn_s_memtime();
+        unsigned long long gs0 = wres0, gs1 = wres0, gs2 = wres0, gs3 = wres0;
+        (void)gs0; (void)gs1; (void)gs2; (void)gs3;
+#endif
         if (worker && !void_blk) {
         uint32_t xs16[BSA];
 #pragma unroll
@@ -1163,7 +1245,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         STAMP(1);
 
         // ---------------- B: owner phase, wave k resolves sample k against the snapshot ----------------
-#ifdef RRT_STAMPS
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
         const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
         uint32_t my_open = 0, my_ntests = 0, my_tcells = 0;  // single-wave owner of a blocked sample: see below
@@ -1176,13 +1258,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         for (int pass = 0;; ++pass) {  // (once, except WIDE with samples left behind blocked ones)
         my_open = 0;
         if constexpr (WPS == 1) {
-#ifdef RRT_EXP_PRIO
-        // the arbiter issues the oldest wave first: without help the owners of the later samples of a SIMD fall behind and
-        // everybody waits for them at the barrier
-        if (wave >= 12) __builtin_amdgcn_s_setprio(3);
-        else if (wave >= 8) __builtin_amdgcn_s_setprio(2);
-        else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
         // A sample whose two cheapest candidates are blocked leaves its open candidates in its list; behind the barrier ALL waves
         // of the workgroup test them, four lines of sight per wave and memory round trip (one wave on its own walks them lane by
         // lane, four round trips, while the other fifteen wait for it: it was a third of a single-wave owner's block).
@@ -1247,7 +1322,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             uint32_t pi = NONE, nnear = 0, ntests = 0, tcells = 0;
             const double cnear_s = Vs + sqrt_u24(d2s);
             WST(5);
-#ifdef RRT_STAMPS
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
             const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
 #endif
             float amin = 0.0f;
@@ -1266,7 +1341,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             } else if (star) {
                 snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);  // no block node is in the cells yet
             }
-#ifdef RRT_STAMPS
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
             wcyc_los += __builtin_amdgcn_s_memtime() - tl0;
 #endif
             WST(6);
@@ -1295,14 +1370,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     r.pr[p2] = pr[p2];
                     r.pdup[p2] = pdup[p2];
                 }
+#pragma unroll
+                for (int w = 0; w < PL_WORDS; ++w) r.plist[w] = 0;  // (no list: flags bits 8-15 are zero)
                 brec[0][sidx] = r;
             }
             if (!WIDE || my_open != 0) break;
             k = take_ticket();
         }
-#ifdef RRT_EXP_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         } else {
             // ---- a group of WPS waves per sample: every wave streams its share of the cells; the group's first wave (leader)
             //      combines, tests lines of sight and writes the record; blocked-candidate lists are tested by all WPS waves ----
@@ -1345,6 +1419,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 tt.init();
                 uint32_t hp = 0, nd2 = NONE, nidx = NONE;
                 if (act) stream_cells(Xk, j0, false, cnear_s, -1.0, 0u, part, WPS, tt, hp, own_nlist, nd2, nidx);  // (grid_nn: no bound yet)
+#ifdef RRT_STAMPS
+                gs0 = __builtin_amdgcn_s_memtime();
+#endif
                 if (lane == 0) {
                     GSlot sl_;
                     sl_.c1 = tt.c1;
@@ -1360,6 +1437,63 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 __syncthreads();
             }
+            if constexpr (FASTL) {
+                // While the group's leader combines the shares and tests the snapshot's candidates, the other waves test the lines of
+                // sight from the samples IN FLIGHT within r_rewire (the two blocks ahead of the commit, the earlier samples of this
+                // block) to this sample, four per wave and memory round trip: should one of them be inserted and turn out the cheaper
+                // parent, the committer has the answer (rrt.py:519) in the record.  Entry e = the e-th such sample, oldest block first.
+                if (!lead && act && star && rad < 64) {
+                    const u64 below = (1ull << lane) - 1ull;
+                    uint32_t xo_[NP + 1], base = 0;
+                    int ent_[NP + 1];
+#pragma unroll
+                    for (int s_ = 0; s_ <= NP; ++s_) {  // set 0 = the oldest previous block ... NP = this block
+                        uint32_t xo;
+                        bool in;
+                        if (s_ < NP) {
+                            xo = xqp_lds[NP - 1 - s_][lane];
+                            in = (NP - 1 - s_) < nprev && dist2(xo, Xk) < r2;
+                        } else {
+                            xo = (lane < sidx) ? xq_lds[lane] : Xk;
+                            in = lane < sidx && dist2(xo, Xk) < r2;
+                        }
+                        const u64 m = __ballot(in);
+                        ent_[s_] = in ? (int)(base + (uint32_t)__builtin_popcountll(m & below)) : -1;
+                        xo_[s_] = xo;
+                        base += (uint32_t)__builtin_popcountll(m);
+                    }
+                    const uint32_t total = base < (uint32_t)PL_MAX ? base : (uint32_t)PL_MAX;
+                    for (uint32_t e0 = 4u * (uint32_t)(part - 1); e0 < total; e0 += 4u * (uint32_t)(WPS - 1)) {
+                        uint32_t a4[4], id4[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            a4[c] = Xk;
+                            id4[c] = 0;
+#pragma unroll
+                            for (int s_ = 0; s_ <= NP; ++s_) {
+                                const u64 hm = __ballot(ent_[s_] == (int)(e0 + (uint32_t)c));
+                                if (hm != 0) {
+                                    const int hl = (int)__builtin_ctzll(hm);
+                                    a4[c] = (uint32_t)__builtin_amdgcn_readlane((int)xo_[s_], hl);
+                                    id4[c] = (uint32_t)(s_ * 64 + hl);
+                                }
+                            }
+                        }
+                        const int nc = (int)(total - e0 < 4u ? total - e0 : 4u);
+                        bool ok4[4];
+                        int cells4[4];
+                        los_batch_n<4>(og, H, a4, nc, Xk, lane, ok4, cells4);
+                        uint32_t ent = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (lane == c) ent = id4[c] | ((uint32_t)cells4[c] << 8) | (ok4[c] ? 0x8000u : 0u);
+                        if (lane < nc) L.plist[sl][e0 + (uint32_t)lane] = (uint16_t)ent;
+                    }
+                }
+            }
+#ifdef RRT_STAMPS
+            gs1 = __builtin_amdgcn_s_memtime();
+#endif
             bool consume = false;
             double lbc = -1.0;
             uint32_t lbi = 0;
@@ -1403,6 +1537,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         }
                     }
                 }
+#ifdef RRT_STAMPS
+                gs2 = __builtin_amdgcn_s_memtime();
+#endif
                 if (star) {
                     Top2 tt;
                     tt.init();
@@ -1451,6 +1588,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     }
                 }
             }
+#ifdef RRT_STAMPS
+            if (lead) gs3 = __builtin_amdgcn_s_memtime();
+#endif
             if (star) {
                 if (lead && lane == 0) {
                     GCtl c;
@@ -1462,6 +1602,146 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 __syncthreads();
                 const GCtl c = gctl[sl];
+                bool by_queue = false;
+                if constexpr (GQ) {
+                    // A sample whose two cheapest candidates are blocked (7 % of the samples: it sits behind a wall, dozens of cheaper
+                    // vertices do not see it) was its block's straggler: the open candidates sit in the lists of the few waves whose
+                    // share of the record stream held them, and each of those waves walked its list one segment per lane, up to four
+                    // dependent passes of sixteen cell loads -- 20 k cycles, with 64 workers in nearly every block, and the committer's
+                    // fetch of the next block waits for the last record (profiles/r04_experiments.md).  Now every wave prices its parked
+                    // entries and puts the open ones into the group's queue; behind a barrier wave w takes entries 8 w .. 8 w + 7 and
+                    // tests all eight in one memory round trip (64 lanes per segment: the radius is below 64 cells here); behind the
+                    // next the leader picks the first passing entry in (cost, index) order and counts the tests the sequential walk
+                    // makes (rrt.py:515-521).
+                    if (rad < 64) {
+                        RRT_LDS u32x4 *const oq = (RRT_LDS u32x4 *)&brec[1][0] + (size_t)sl * OQCAP;
+#ifdef RRT_STAMPS
+                        unsigned long long qt0 = __builtin_amdgcn_s_memtime(), qt1 = qt0, qt2 = qt0, qt3 = qt0, qt4 = qt0;
+#endif
+                        if (c.consume != 0u) {
+                            const float boundf = screen_of(c.bound);
+                            float am = FINF;
+                            for (uint32_t p0 = 0; p0 < own_nlist; p0 += 64) {
+                                const uint32_t p = p0 + (uint32_t)lane;
+                                u32x4 e = {NONE, 0u, 0u, 0u};
+                                if (p < own_nlist) e = lget(p);  // {index, xy, vcost}
+                                const double V = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                                const uint32_t ed2 = dist2(e.y, Xk);
+                                double cn = f64_inf();
+                                if (p < own_nlist) {
+                                    const float cf = (float)V + __builtin_amdgcn_sqrtf((float)ed2);
+                                    bool below = false;
+                                    if (cf < boundf) {
+                                        const double cx = V + sqrt_u24(ed2);
+                                        below = cx < c.bound;
+                                        if (below && !key_lt(cx, e.x, c.lbc, c.lbi)) cn = cx;
+                                    }
+                                    if (!below) am = __builtin_fminf(am, __builtin_fmaxf(cf * (1.0f - 1.0e-6f) - 4.0e-3f, 0.0f));
+                                }
+                                const bool open = cn < c.bound;
+                                const unsigned long long om = __ballot(open);
+                                if (om != 0) {
+                                    const uint32_t cnt = (uint32_t)__builtin_popcountll(om);
+                                    uint32_t qb = 0;
+                                    if (lane == 0) qb = __hip_atomic_fetch_add(&L.oq_cnt[sl], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    qb = uni32(qb);
+                                    if (qb + cnt > OQCAP) {
+                                        if (lane == 0) L.oq_ovf = 1u;  // (a radius with more open entries than the queue holds: the lists' own walk)
+                                    } else if (open) {
+                                        const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
+                                        oq[qb + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = u32x4{e.x, e.y, (uint32_t)cb, (uint32_t)(cb >> 32)};
+                                    }
+                                }
+                            }
+                            am = wave_min_f32_nonneg(am);
+                            if (lane == 0) gslot[wave].pad[0] = __float_as_uint(am);
+                        }
+#ifdef RRT_STAMPS
+                        qt1 = __builtin_amdgcn_s_memtime();
+#endif
+                        __syncthreads();
+#ifdef RRT_STAMPS
+                        qt2 = __builtin_amdgcn_s_memtime();
+#endif
+                        if (uni32(L.oq_ovf) == 0u) {
+                            by_queue = true;
+                            const uint32_t nq = c.consume != 0u ? uni32(L.oq_cnt[sl]) : 0u;
+                            for (uint32_t e0 = 8u * (uint32_t)part; e0 < nq; e0 += 8u * (uint32_t)WPS) {
+                                const int nc = (int)(nq - e0 < 8u ? nq - e0 : 8u);
+                                uint32_t axy = Xk;
+                                if (lane < nc) axy = oq[e0 + (uint32_t)lane].y;  // (the entry's coordinates; the result of its test goes there)
+                                uint32_t a8[LOSB];
+#pragma unroll
+                                for (int q8 = 0; q8 < LOSB; ++q8) a8[q8] = (uint32_t)__builtin_amdgcn_readlane((int)axy, q8);
+                                bool ok8[LOSB];
+                                int cells8[LOSB];
+                                los_batch(og, H, a8, nc, Xk, lane, ok8, cells8);
+                                uint32_t res = 0;
+#pragma unroll
+                                for (int q8 = 0; q8 < LOSB; ++q8)
+                                    if (lane == q8) res = (uint32_t)cells8[q8] | (ok8[q8] ? 0u : 0x80000000u);
+                                if (lane < nc) oq[e0 + (uint32_t)lane].y = res;  // cells read; bit 31: blocked
+                            }
+#ifdef RRT_STAMPS
+                            qt3 = __builtin_amdgcn_s_memtime();
+#endif
+                            __syncthreads();
+#ifdef RRT_STAMPS
+                            qt4 = __builtin_amdgcn_s_memtime();
+                            if (lead && lane == 0 && c.consume != 0u && g >= 1) {
+                                const int o = (qt4 - wres0 > 30000ull) ? 24 : 16;
+                                atomicAdd(&D->dbg2[o + 0], 1ull);
+                                atomicAdd(&D->dbg2[o + 1], qt0 - gs3);  // gctl + barrier
+                                atomicAdd(&D->dbg2[o + 2], qt1 - qt0);  // pricing into the queue
+                                atomicAdd(&D->dbg2[o + 3], qt2 - qt1);  // barrier
+                                atomicAdd(&D->dbg2[o + 4], qt3 - qt2);  // tests
+                                atomicAdd(&D->dbg2[o + 5], qt4 - qt3);  // barrier
+                                atomicAdd(&D->dbg2[o + 6], (unsigned long long)nq);
+                                atomicAdd(&D->dbg2[o + 7], gs3 - wres0);  // everything in front of the blocked-candidate path
+                            }
+#endif
+                            if (lead && c.consume != 0u) {
+                                double wc = f64_inf();
+                                uint32_t wi = NONE;
+                                for (uint32_t p0 = 0; p0 < nq; p0 += 64) {  // the first passing entry in (cost, index) order
+                                    const uint32_t pq = p0 + (uint32_t)lane;
+                                    double cn = f64_inf();
+                                    uint32_t ci = NONE;
+                                    if (pq < nq) {
+                                        const u32x4 e = oq[pq];
+                                        if ((e.y >> 31) == 0u) {
+                                            cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                                            ci = e.x;
+                                        }
+                                    }
+                                    wave_min_f64_idx(cn, ci);
+                                    if (ci != NONE && key_lt(cn, ci, wc, wi)) {
+                                        wc = cn;
+                                        wi = ci;
+                                    }
+                                }
+                                uint32_t nt = 0, tcl = 0;  // the tests the sequential walk makes: up to and including that entry, or all
+                                for (uint32_t pq = (uint32_t)lane; pq < nq; pq += 64) {
+                                    const u32x4 e = oq[pq];
+                                    const double cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                                    if (wi == NONE || !key_lt(wc, wi, cn, e.x)) {
+                                        nt += 1;
+                                        tcl += e.y & 0x7fffffffu;
+                                    }
+                                }
+                                ntests += wave_sum_u32(nt);
+                                tcells += wave_sum_u32(tcl);
+                                pc = wc;
+                                pi = wi;
+                                float am = FINF;
+                                if (lane < WPS) am = __uint_as_float(gslot[sl * WPS + lane].pad[0]);
+                                amin = grid_nn ? wave_min_f32_nonneg(am) : 0.0f;
+                                if (lane == 0) L.oq_cnt[sl] = 0;  // (the next block's waves append behind its own barriers)
+                            }
+                        }
+                    }
+                }
+                if (!by_queue) {
                 if (c.consume != 0u) {  // every wave of the group: its own parked entries above the lower bound
                     double wc;
                     uint32_t wi, nval;
@@ -1516,7 +1796,26 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     tcells += wave_sum_u32(tcl);
                     amin = grid_nn ? wave_min_f32_nonneg(am) : 0.0f;  // (shares that streamed under the bound parked nothing above it)
                 }
+                if (GQ && lead && lane == 0) {  // (the queue path gave up: overflow)
+                    L.oq_cnt[sl] = 0;
+                    L.oq_ovf = 0;
+                }
+                }  // !by_queue
             }
+#ifdef RRT_STAMPS
+            if (lead && act && lane == 0 && PIPE && g >= 1) {  // where a group's time goes: all blocks [8..], blocks of more than 32 k cycles [0..]
+                const unsigned long long ge = __builtin_amdgcn_s_memtime();
+                const int o = (ge - wres0 > 32000ull) ? 0 : 8;
+                atomicAdd(&D->dbg2[o + 0], 1ull);
+                atomicAdd(&D->dbg2[o + 1], gs0 - wres0);  // block top .. own share of the stream done
+                atomicAdd(&D->dbg2[o + 2], gs1 - gs0);    // .. first barrier passed (the slowest wave's share)
+                atomicAdd(&D->dbg2[o + 3], gs2 - gs1);    // .. leader: nearest, its cost, line of sight, masks
+                atomicAdd(&D->dbg2[o + 4], gs3 - gs2);    // .. leader: the two cheapest candidates' lines of sight
+                atomicAdd(&D->dbg2[o + 5], ge - gs3);     // .. the blocked-candidate barriers and lists
+                if (consume) atomicAdd(&D->dbg2[o + 6], 1ull);
+                if (nnear == 0) atomicAdd(&D->dbg2[o + 7], 1ull);
+            }
+#endif
             if (lead && act && lane == 0) {
                 BRec r;
                 r.d2s = d2s;
@@ -1539,10 +1838,22 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     r.pr[p2] = pr[p2];
                     r.pdup[p2] = pdup[p2];
                 }
+#pragma unroll
+                for (int w = 0; w < PL_WORDS; ++w) r.plist[w] = 0;
+                if constexpr (FASTL) {  // the group's list (its waves filled it in front of the last barriers); a radius beyond the batched test: void
+                    uint32_t nent = (uint32_t)__builtin_popcountll(rmask);
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) nent += (uint32_t)__builtin_popcountll(pr[p2]);
+                    if (rad >= 64 && nent != 0) nent = 255u;
+                    r.flags |= (nent < 255u ? nent : 255u) << 8;
+                    const RRT_LDS u64 *pl = (const RRT_LDS u64 *)&L.plist[sl][0];
+#pragma unroll
+                    for (int w = 0; w < PL_WORDS; ++w) r.plist[w] = pl[w];
+                }
                 brec[0][sidx] = r;
             }
         }
-#ifdef RRT_STAMPS
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
         wcyc_acc += __builtin_amdgcn_s_memtime() - tb0;
 #endif
         STAMP(2);
@@ -1558,7 +1869,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     for (uint32_t c = (uint32_t)((wave - w) & (NWAVE - 1)); c * 4u < n; c += NWAVE) {  // this wave's groups of four candidates
                         const uint32_t pq = c * 4u + (uint32_t)(lane & 3);
                         uint32_t axy = Xw;
-                        if (pq < n) axy = node_xy(lget_w(w, pq).x);
+                        if (pq < n) axy = lget_w(w, pq).y;
                         uint32_t a4[4];
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) a4[q4] = (uint32_t)__builtin_amdgcn_readlane((int)axy, q4);
@@ -1622,6 +1933,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // ---------------- a pipelined team's workers: hand the records of block s over and, instead of waiting for its commit,
         //                  take the nodes of the commit of block s - 1 and go on with block s + 1 ----------------
         if (PIPE && g > 0) {
+#ifdef RRT_STAMPS
+            if (t == 0 && g <= 64) {
+                const unsigned long long dres = __builtin_amdgcn_s_memtime() - wres0;
+                if (dres > 26000ull) D->dbg2[192 + g - 1] += 1;
+                if (dres > 32000ull) D->dbg2[256 + g - 1] += 1;
+                if (dres > 40000ull) D->dbg2[320 + g - 1] += 1;
+                if (dres > D->dbg2[384 + g - 1]) D->dbg2[384 + g - 1] = dres;
+            }
+#endif
             DBGT(0);
             const bool more = i0 + nb < n;
             const bool take = (int)epoch > LAG && (more || pipe_inf);  // there is a commit to take (an Informed worker always looks)
@@ -1633,6 +1953,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains, then signals
                 }
                 if (lane == 0) __hip_atomic_store(t_arrive + 32 * g, epoch, RRT_RLX_AGENT);
+                if (g == 1) TSMARK(epoch, 5);
+                if (g == 8) TSMARK(epoch, 8);
             }
             // The commit this worker has to take next is some way off: meanwhile it scans the nodes it already has for the NEXT
             // block's samples (known: only an Informed block can be cut short); after the take only the steps that hold new
@@ -1659,6 +1981,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 DBGT(1);
                 if (take) {
                     ok = team_wait(t_go, epoch - LAG, t_fail);
+                    if (g == 1) TSMARK(epoch, 6);
+                    if (g == 8) TSMARK(epoch, 9);
                     DBGT(2);
                     if (!grid_nn) {  // (the scan of the node array reads it with plain loads)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ONE acquire per workgroup: drops this CU's L1
@@ -1717,6 +2041,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
             }
             __syncthreads();
+            if (wave == 0 && g == 1) TSMARK(epoch, 7);
+            if (wave == 0 && g == 8) TSMARK(epoch, 10);
             DBGT(3);
             continue;
         }
@@ -1798,6 +2124,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         u64 popt = 0, inter = 0, known = 0, aknown = 0;  // parallel rounds: samples whose final result is known, the accepted ones
         bool rounds_on = false;
         bool pbad = false;  // an inserted sample of a previous block affects this sample
+        // FASTC (a committer whose records carry the in-flight lines of sight, PL_MAX): psurv = the list entries of PREVIOUS blocks
+        // that were inserted and would be tried as this sample's parent before the snapshot's choice (their costs are exact);
+        // lists: this sample's list is usable (not void); such a sample is settled lane-parallel, without a round (fast_settle)
+        constexpr bool FASTC = PIPE && BSM < 16;
+        uint32_t psurv = 0, nent = 0;
+        bool lists = false;
         // harm: the earlier samples within r_rewire that, once inserted at their cost, would be tried as this sample's parent
         // before the snapshot's choice: cost-through-it < cost through the snapshot parent (ties go to the lower index = the
         // snapshot, rrt.py:518-521).  A single-precision bound settles almost every pair; bit k is re-evaluated when sample
@@ -1815,7 +2147,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         // ones (ap[], their count bases jp[]): any wave.  Its record in LDS is replaced by the final one; returns acceptance and cost.
         // Block references: 0x80000000 + 64 * set + kk with set 0 = the oldest previous block ... NP = this block.
         auto resolve_sample = [&](int k, u64 acc_k, const u64 (&ap)[NP], const int (&jp)[NP], bool check_full, bool &acc, double &cbest) {
-#ifdef RRT_STAMPS
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
             const unsigned long long rs0 = __builtin_amdgcn_s_memtime();
             bool rs_redo = false;
 #endif
@@ -1897,7 +2229,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                                                           // part (a parent found below the old bound stays the cheapest: same tests)
                         ntests = 0;
                         tcells = 0;
-#ifdef RRT_STAMPS
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
                         rs_redo = true;
 #endif
                         snapshot_parent(Xk, snapj, true, cnear, pc, pi, nnear, ntests, tcells);
@@ -1980,12 +2312,94 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 f.flags = rk.flags | 2u;
                 newcost[k] = cbest;
             }
-#ifdef RRT_STAMPS
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
             if (t == 0) {
                 dbg[rs_redo ? 10 : 12] += __builtin_amdgcn_s_memtime() - rs0;
                 dbg[rs_redo ? 11 : 5] += 1;
             }
 #endif
+        };
+
+        // FASTC: this lane's sample keeps its nearest vertex and its acceptance; inserted samples in flight (hm: of this block, by sample;
+        // ps: of the previous blocks, by list position) are cheaper than its snapshot parent.  The walk of rrt.py:515-521 tries them in
+        // (cost, index) order until one has a free line of sight -- the record's list holds every such test's answer, so the lane
+        // settles it alone: the first free one becomes the parent; the blocked ones in front of it (or all of them, if none is free) are
+        // the tests the walk made.  The sample's record in LDS is replaced by the final one, as a round would.
+        auto fast_settle = [&](u64 hm, uint32_t ps, uint32_t ne, u64 rmask_own) {
+            if constexpr (FASTC) {
+                BRec &f = brec[bsel][lane];
+                // candidates by list position: the previous blocks' (ps), and this block's (sample kk sits behind all previous-block
+                // entries, at its rank among the earlier samples of this block within r_rewire)
+                const uint32_t own0 = ne - (uint32_t)__builtin_popcountll(rmask_own);
+                uint32_t cm = ps;
+                while (hm) {
+                    const int kk = __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    cm |= 1u << (own0 + (uint32_t)__builtin_popcountll(rmask_own & lowmask64(kk)));
+                }
+                auto entry_of = [&](uint32_t pe) -> uint32_t { return (uint32_t)(f.plist[pe >> 2] >> (16u * (pe & 3u))) & 0xffffu; };
+                auto entry_cost = [&](uint32_t e16) -> double {
+                    const int kk = (int)(e16 & 63u), set = (int)((e16 >> 6) & 3u);
+                    if (set == NP) return newcost[kk] + sqrt_u24(dist2(xq_lds[kk], xv));
+                    return prevcost[NP - 1 - set][kk] + sqrt_u24(dist2(xqp_lds[NP - 1 - set][kk], xv));
+                };
+                double bc = f64_inf();
+                uint32_t bref = NONE, bcells = 0, nblocked = 0;
+                for (uint32_t m = cm; m != 0; m &= m - 1) {
+                    const uint32_t e16 = entry_of((uint32_t)__builtin_ctz(m));
+                    if ((e16 >> 15) == 0u) {  // blocked
+                        nblocked += 1;
+                        continue;
+                    }
+                    const double c = entry_cost(e16);
+                    const uint32_t ref = 0x80000000u + (e16 & 0xffu);  // (64 * set + sample: compares like the node index it stands for)
+                    if (key_lt(c, ref, bc, bref)) {
+                        bc = c;
+                        bref = ref;
+                        bcells = (e16 >> 8) & 127u;
+                    }
+                }
+                uint32_t nt = bref != NONE ? 1u : 0u, tc = bcells;
+                if (nblocked != 0) {  // blocked candidates: the ones in front of the winner (all, without one) were tested
+                    for (uint32_t m = cm; m != 0; m &= m - 1) {
+                        const uint32_t e16 = entry_of((uint32_t)__builtin_ctz(m));
+                        if ((e16 >> 15) != 0u) continue;
+                        if (bref == NONE || key_lt(entry_cost(e16), 0x80000000u + (e16 & 0xffu), bc, bref)) {
+                            nt += 1;
+                            tc += (e16 >> 8) & 127u;
+                        }
+                    }
+                }
+                const uint32_t ps0 = f.pstat;
+                f.pstat = (((ps0 >> 20) + nt) << 20) | (((ps0 & 0xfffffu) + tc) & 0xfffffu);
+                if (bref != NONE) {
+                    f.cbest = bc;
+                    f.vbest = bref;
+                    newcost[lane] = bc;
+                }
+            }
+        };
+
+        // One wave: the SB records of block `ep` from the hand-off area into brec[half].  The block's records are one contiguous
+        // piece (64 x BREC_WORDS x 8 bytes), so the wave takes it as whole 16-byte chunks, lane by lane: 80 cache lines instead of
+        // 64 x BREC_WORDS separate 8-byte requests to lines another XCD wrote (that fetch was 8 k cycles, profiles/r04_experiments.md).
+        auto fetch_records = [&](uint32_t ep, int half) {
+            constexpr int NCH = SB * BREC_WORDS * 8 / 16, NIT = (NCH + 63) / 64;  // (the SB records of a block are the front of its 64-record slot)
+            static_assert(NCH * 16 == SB * BREC_WORDS * 8, "whole chunks");
+            const unsigned char *src = tb + TEAM_OFF_REC + (size_t)(ep % NSLOT) * 64 * BREC_WORDS * 8;
+            u32x4 v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = it * 64 + lane;
+                v[it] = ld_b128_agent(src + 16 * (c < NCH ? c : NCH - 1));
+            }
+            fence_b128s(v);
+            RRT_LDS u32x4 *dst = (RRT_LDS u32x4 *)&brec[half][0];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = it * 64 + lane;
+                if (c < NCH) dst[c] = v[it];
+            }
         };
 
         // ---- part A (wave 0): the records, the optimistic picture, and for a pipelined committer the samples that can be
@@ -1994,10 +2408,12 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (G > 1) {  // the other members' records: poll the arrival flags, then loads that bypass the L1
                 DBGT(7);
                 if (PIPE && prefetched) {  // wave 1 fetched them during the last commit
-                    remote_ok = uni32(pre_state) == 1u;
+                    remote_ok = uni32(pre_state[bsel]) == 1u;
                 } else {
                     remote_ok = team_wait_all(t_arrive, 1, PIPE ? G : G - 1, epoch, t_fail, lane);
-                    if (remote_ok && (PIPE || lane >= BSM) && lane < nb) {
+                    if (PIPE) {
+                        if (remote_ok) fetch_records(epoch, bsel);
+                    } else if (remote_ok && lane >= BSM && lane < nb) {
                         const gu64 *src = t_rec + (size_t)(epoch % NSLOT) * 64 * BREC_WORDS + (size_t)lane * BREC_WORDS;
                         BRecWords u;
 #pragma unroll
@@ -2007,6 +2423,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
             }
             DBGT(7);
+            if (ROLE == ROLE_COMMIT) TSMARK(epoch, 11);
             if (!remote_ok) {
                 if (lane == 0) blk.pad0 = 1;
             } else {
@@ -2014,6 +2431,14 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 acc0 = lane < nb && (r.los_s >> 31) != 0 && (r.flags & 1u) == 0;  // accepted if nothing in the block interferes
                 goalhit = informed && lane < nb && dist2(xv, xg) < goal_d2;
                 if (lane < nb) newcost[lane] = r.cbest;  // optimistic (snapshot-resolved) cost; exact once the sample has committed
+                if (PIPE && epoch == 1) {
+#pragma unroll
+                    for (int p2 = 0; p2 < NP; ++p2) jp0[p2] = j0;
+                }
+                if constexpr (FASTC) {
+                    nent = (r.flags >> 8) & 0xffu;
+                    lists = lane < nb && nent <= (uint32_t)PL_MAX;
+                }
                 if (lane < nb && acc0) {
                     u64 rm = r.rmask;
                     while (rm) {
@@ -2023,10 +2448,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     }
                 }
                 // pipelined: the nodes the previous block inserted are exact; the samples of this block were resolved without them
-                if (PIPE && epoch == 1) {
-#pragma unroll
-                    for (int p2 = 0; p2 < NP; ++p2) jp0[p2] = j0;
-                }
                 if (PIPE && lane < nb) {
 #pragma unroll
                     for (int p2 = 0; p2 < NP; ++p2) {
@@ -2034,10 +2455,18 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         pbad = pbad || ((r.pnn[p2] | r.pdup[p2]) & A_prev[p2]) != 0;
                         if (acc0) {
                             u64 rm = r.pr[p2] & A_prev[p2];
+                            // (FASTC: the list holds the samples within r_rewire oldest block first, sample order within a block: the entry of
+                            //  sample kk of previous block p2 sits behind the entries of the older blocks, at its rank among the block's)
+                            uint32_t pbase = 0;
+#pragma unroll
+                            for (int p3 = NP - 1; p3 > p2; --p3) pbase += (uint32_t)__builtin_popcountll(r.pr[p3]);
                             while (rm) {
                                 const int kk = __builtin_ctzll(rm);
                                 rm &= rm - 1;
-                                if (cheaper_through(prevcost[p2][kk], dist2(xqp_lds[p2][kk], xv), r.cbest)) pbad = true;
+                                if (cheaper_through(prevcost[p2][kk], dist2(xqp_lds[p2][kk], xv), r.cbest)) {
+                                    if (FASTC && lists) psurv |= 1u << (pbase + (uint32_t)__builtin_popcountll(r.pr[p2] & lowmask64(kk)));
+                                    else pbad = true;
+                                }
                             }
                         }
                     }
@@ -2049,7 +2478,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     // samples it settled and the ones that turn out to keep their snapshot result given those.
                     popt = __ballot(acc0);
                     inter = (r.nnmask | r.dupmask | r.rmask) & ltmask;
-                    const bool slow0 = lane < nb && (((r.nnmask | r.dupmask | harm) & popt & ltmask) != 0 || pbad);
+                    const bool slow0 = lane < nb && (((r.nnmask | r.dupmask | harm) & popt & ltmask) != 0 || pbad || psurv != 0);
                     u64 taint = __ballot(slow0);
                     for (int it = 0; it < 6; ++it) {
                         const u64 t2 = taint | __ballot(lane < nb && (inter & taint) != 0);
@@ -2093,14 +2522,40 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         u64 L0 = 0;
                         for (;;) {  // samples whose earlier interacting samples are all known: unaffected -> known; affected -> this round
                             const bool ready = lane < nb && (known & lbit) == 0 && (inter & ~known) == 0;
-                            const bool dirty = ((r.nnmask | r.dupmask | harm) & aknown & ltmask) != 0 || pbad || (goalhit && acc0);
-                            const u64 cb = __ballot(ready && !dirty);
-                            if (cb == 0) {
-                                L0 = __ballot(ready && dirty && !goalhit);  // (a goal hit ends or cuts the block: ordered loop)
+                            const bool hd = (harm & aknown & ltmask) != 0;  // an inserted sample of this block would be tried before the snapshot's choice
+                            // sd: the sample has to be resolved again (a round); fd: only its parent is in question and the record holds
+                            // every line of sight that question needs -- settled here, by its lane
+                            const bool sd = ((r.nnmask | r.dupmask) & aknown & ltmask) != 0 || pbad || (goalhit && acc0) || (hd && !(FASTC && lists));
+                            const bool fd = FASTC && !sd && (hd || psurv != 0);
+                            const u64 cb = __ballot(ready && !sd && !fd);
+                            const u64 fb = FASTC ? __ballot(ready && fd) : 0ull;
+                            if (cb == 0 && fb == 0) {
+                                L0 = __ballot(ready && sd && !goalhit);  // (a goal hit ends or cuts the block: ordered loop)
                                 break;
                             }
                             known |= cb;
                             aknown |= cb & popt;
+                            if constexpr (FASTC) {
+                                if (fb != 0) {
+                                    if (ready && fd) fast_settle(harm & aknown & ltmask, psurv, nent, r.rmask);
+                                    fin |= fb;  // final, like the samples a round settled (all of them were accepted at the snapshot and stay so)
+                                    fin_acc |= fb;
+                                    known |= fb;
+                                    aknown |= fb;
+#ifdef RRT_STAMPS
+                                    if (t == 0) dbg[13] += (unsigned long long)__builtin_popcountll(fb) << 32;  // (upper half: samples settled by their lanes)
+#endif
+                                    // their costs are exact now: the later samples they are a candidate parent of look again
+                                    u64 rm = r.rmask & fb;
+                                    if (lane < nb && acc0 && (known & lbit) == 0) {
+                                        while (rm) {
+                                            const int kk = __builtin_ctzll(rm);
+                                            rm &= rm - 1;
+                                            harm = (harm & ~(1ull << kk)) | (harmful(kk) ? (1ull << kk) : 0ull);
+                                        }
+                                    }
+                                }
+                            }
                         }
                         // the first CW of them (one per wave of this workgroup), in sample order: lane k knows its place in the list
                         const uint32_t place = (uint32_t)__builtin_popcountll(L0 & ltmask);
@@ -2145,33 +2600,54 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
         }
         DBGT(2);
-        // A pipelined committer's wave 1 meanwhile fetches the next block: its samples, and (workers that run ahead have
-        // handed them over already) its records.  Only an Informed block can end early, so the next block is known.
+        // A pipelined committer's last two waves meanwhile fetch the next block: its records (workers that run ahead have handed them
+        // over already) and its samples.  Only an Informed block can end early, so the next block is known.  (Behind the rounds, not
+        // at the top of the block: there the last records are still ~9 k cycles away and the rounds' first barrier waits for this
+        // wave -- measured, profiles/r04_experiments.md.)
         const bool pre_next = PIPE && (!informed || LAG >= 2) && i0 + nb < n;
         const bool pre_smp = pre_next && !informed;
-        if (PIPE && wave == 1 && pre_next) {
+        if (PIPE && wave == CW - 1 && pre_next) {
 #ifdef RRT_STAMPS
             const unsigned long long pf0 = __builtin_amdgcn_s_memtime();
 #endif
-            const int in = i0 + nb;
-            const int nbn = (n - in) < SB ? (n - in) : SB;
-            const bool ok = team_wait_all(t_arrive, 1, G, epoch + 1, t_fail, lane);
-            if (ok && lane < nbn) {
-                const gu64 *src = t_rec + (size_t)((epoch + 1) % NSLOT) * 64 * BREC_WORDS + (size_t)lane * BREC_WORDS;
-                BRecWords u;
-#pragma unroll
-                for (int w = 0; w < BREC_WORDS; ++w) u.w[w] = __hip_atomic_load(src + w, RRT_RLX_AGENT);
-                brec[bsel ^ 1][lane] = u.r;
+            TSMARK(epoch, 2);
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
+            bool ok = true;  // team_wait_all, counting who is late
+            {
+                const u64 t0w = wall_clock64();
+                u64 lastmiss = 0;
+                for (;;) {
+                    const bool mine = lane < G ? __hip_atomic_load(t_arrive + 32 * (1 + lane), RRT_RLX_AGENT) >= epoch + 1 : true;
+                    const u64 miss = __ballot(!mine);
+                    if (miss == 0) break;
+                    if (!mine) D->dbg2[lane] += 1;
+                    lastmiss = miss;
+                    if (__hip_atomic_load(t_fail, RRT_RLX_AGENT) != 0u || wall_clock64() - t0w > TEAM_TIMEOUT_TICKS) {
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (lastmiss != 0 && (lastmiss & (lastmiss - 1)) == 0 && ((lastmiss >> lane) & 1ull)) D->dbg2[64 + lane] += 1;
             }
-            if (lane == 0) pre_state = ok ? 1u : 2u;
+#else
+            const bool ok = team_wait_all(t_arrive, 1, G, epoch + 1, t_fail, lane);
+#endif
 #ifdef RRT_STAMPS
-            if (lane == 0) dbg[14] += __builtin_amdgcn_s_memtime() - pf0;
+            const unsigned long long pf1 = __builtin_amdgcn_s_memtime();
+#endif
+            TSMARK(epoch, 3);
+            if (ok) fetch_records(epoch + 1, bsel ^ 1);
+            TSMARK(epoch, 4);
+            if (lane == 0) pre_state[bsel ^ 1] = ok ? 1u : 2u;
+#ifdef RRT_STAMPS
+            if (lane == 0) dbg[14] += ((__builtin_amdgcn_s_memtime() - pf0) & 0xffffffffull) | ((pf1 - pf0) << 32);  // (upper half: the wait for the flags)
 #endif
         }
-        if (PIPE && wave == 2 && pre_smp) {  // (the samples: a wave of their own, one memory round trip less in a row)
+        if (PIPE && wave == CW - 2 && pre_smp) {  // (the samples: a wave of their own, one memory round trip less in a row)
             const int in = i0 + nb;
             const int nbn = (n - in) < SB ? (n - in) : SB;
-            if (lane < nbn) xq_next[lane] = at32(samples, (uint32_t)(in + lane));
+            if (lane < nbn) xq_next[bsel ^ 1][lane] = at32(samples, (uint32_t)(in + lane));
         }
         // ---- part B (wave 0): decide in order, store, publish ----
         if (wave == 0 && remote_ok) {
@@ -2188,7 +2664,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 // A sample keeps its snapshot result unless an earlier inserted sample of the block is nearer than its nearest,
                 // sits on its cell, or (accepted samples only) is a harmful candidate parent.
                 const bool slow = lane >= cur && lane < nb && (fin & lbit) == 0 &&
-                                  (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || pbad || (goalhit && acc0));
+                                  (((r.nnmask | r.dupmask | harm) & Aopt) != 0 || pbad || psurv != 0 || (goalhit && acc0));
                 const unsigned long long bad = __ballot(slow);
                 const int k0 = bad ? (int)__builtin_ctzll(bad) : nb;
                 acc_exact |= pend & lowmask64(k0) & ~lowmask64(cur);
@@ -2324,6 +2800,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             // state first (write-through), then everything the commit stored, then the flag
             DBGT(9);
             if (G > 1) publish_state(epoch, (PIPE && cut) ? ST_FLAG_RESTART : 0);
+            if (ROLE == ROLE_COMMIT) TSMARK(epoch, 1);
             DBGT(4);
         }
         STAMP(4);
@@ -2405,6 +2882,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 if (PIPE && t == 0 && g == 1)
 #pragma unroll
                     for (int k = 0; k < 16; ++k) D->wcyc[16 + k] = dbg[k];
+                if (PIPE && t == 0 && g >= 1 && g <= 64) D->dbg2[128 + g - 1] = dbg[0];
 #endif
                 return;
             }

@@ -645,6 +645,10 @@ static void arm_desc(QDesc &d) {
     d.n_words = 0;
     for (auto &c : d.cyc) c = 0;
     for (auto &c : d.wcyc) c = 0;
+#ifdef RRT_STAMPS
+    for (auto &c : d.dbg2) c = 0;
+    for (auto &c : d.ts) c = 0;
+#endif
 }
 
 extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu) {
@@ -985,6 +989,36 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
     HIPCHK(ctx, wait_stream_spin(ctx->stream));
     cu_release(ctx->device, b->claimed_cus);  // the launch is over: its compute units are free for the launches of other batches
     b->claimed_cus = 0;
+#ifdef RRT_STAMPS
+    if (getenv("RRT_STAMPS_DUMP")) {  // diagnostic build only: who the committer's record fetch waits for (QDesc::dbg2)
+        const QDesc &d0 = b->h_desc[0];
+        fprintf(stderr, "dbg2 groups of slow blocks (> 32 k) [count, own stream, first barrier, nearest + LoS, top-2 LoS, tail, consume, empty ball]:");
+        for (int m = 0; m < 8; ++m) fprintf(stderr, " %llu", d0.dbg2[m]);
+        fprintf(stderr, "\ndbg2 groups of the other blocks:");
+        for (int m = 8; m < 16; ++m) fprintf(stderr, " %llu", d0.dbg2[m]);
+        fprintf(stderr, "\ndbg2 groups queue, fast [count, gctl barrier, pricing, barrier, tests, barrier, queue entries, time before]:");
+        for (int m = 16; m < 24; ++m) fprintf(stderr, " %llu", d0.dbg2[m]);
+        fprintf(stderr, "\ndbg2 groups queue, slow (> 30 k at the last barrier):");
+        for (int m = 24; m < 32; ++m) fprintf(stderr, " %llu", d0.dbg2[m]);
+        fprintf(stderr, "\ndbg2 missing-polls:");
+        for (int m = 0; m < 64; ++m) fprintf(stderr, " %llu", d0.dbg2[m]);
+        fprintf(stderr, "\ndbg2 last-to-arrive:");
+        for (int m = 0; m < 64; ++m) fprintf(stderr, " %llu", d0.dbg2[64 + m]);
+        fprintf(stderr, "\ndbg2 resolve-cycles:");
+        for (int m = 0; m < 64; ++m) fprintf(stderr, " %llu", d0.dbg2[128 + m]);
+        fprintf(stderr, "\n");
+        for (int a = 0; a < 4; ++a) {
+            fprintf(stderr, "dbg2 %s:", a == 0 ? "resolve>26k" : a == 1 ? "resolve>32k" : a == 2 ? "resolve>40k" : "resolve-max");
+            for (int m = 0; m < 64; ++m) fprintf(stderr, " %llu", d0.dbg2[192 + 64 * a + m]);
+            fprintf(stderr, "\n");
+        }
+        for (int k = 0; k < 32; ++k) {
+            fprintf(stderr, "ts block %d:", 300 + k);
+            for (int e = 0; e < 16; ++e) fprintf(stderr, " %lld", d0.ts[k * 16 + e] ? (long long)(d0.ts[k * 16 + e] - d0.ts[0]) : -1ll);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     // A team whose members were not resident together stops at a block boundary with a consistent tree (ST_TEAM_FAIL, a
     // bounded wait expired).  Teams are only an optimisation: the batch continues from there with one CU per query.
     bool team_fail = false;
@@ -1149,13 +1183,19 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
+std::string g_rccl_path;  // rrt_comm_use_library: the library to open instead of librccl.so.1 (empty: the default)
 
 std::mutex g_rccl_mutex;  // contexts of different host threads may ask for the library at the same time
 
 int rccl_load(rrt_ctx *ctx) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle) return RRT_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    void *h = nullptr;
+    if (!g_rccl_path.empty()) {
+        h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(ctx, RRT_E_COMM, "cannot open the collective library %s: %s", g_rccl_path.c_str(), dlerror());
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(ctx, RRT_E_COMM, "cannot open librccl.so.1: %s", dlerror());
@@ -1192,6 +1232,13 @@ __global__ void slab_meta_kernel(const QDesc *desc, int Q, int32_t *meta) {
     }
 }
 }  // namespace
+
+extern "C" int rrt_comm_use_library(const char *path) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return fail(nullptr, RRT_E_COMM, "rrt_comm_use_library: a collective library is already open in this process");
+    g_rccl_path = path ? path : "";
+    return RRT_OK;
+}
 
 extern "C" int rrt_comm_unique_id(uint8_t id[RRT_COMM_ID_BYTES]) {
     if (!id) return fail(nullptr, RRT_E_ARG, "rrt_comm_unique_id: NULL");

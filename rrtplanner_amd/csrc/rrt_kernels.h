@@ -49,6 +49,12 @@ struct QDesc {
     double rho;          // Dubins planners (alg 3 / 4): turning radius in cells, number of headings, start / goal heading index
     int32_t nh, hs, hg, pad_;
     unsigned long long n_words;  // Dubins planners: dub_shortest() evaluations made (the byte / flop model counts one per near-set entry)
+#ifdef RRT_STAMPS
+    // diagnostic build, pipelined teams: per worker m = member - 1: [m] polls of the committer's record fetch during which m's records were
+    // still missing, [64 + m] blocks in which m was the LAST to arrive, [128 + m] the worker's own cycles in its resolve phase
+    unsigned long long dbg2[448];  // (+ [192 + m], [256 + m], [320 + m]: blocks whose resolve phase took m more than 26 k / 32 k / 40 k cycles, [384 + m]: its longest)
+    unsigned long long ts[32 * 16];  // wall-clock (10 ns) time stamps of 32 consecutive blocks, 16 events each (rrt_block.h: TSMARK)
+#endif
 };
 
 struct BatchView {
@@ -339,7 +345,7 @@ __device__ __forceinline__ void go2goal_phase(const uint8_t *og, int H, const ui
     }
 }
 
-#ifdef RRT_STAMPS
+#if defined(RRT_STAMPS) && !defined(RRT_STAMPS_LIGHT)
 #define STAMP(k)                                                \
     do {                                                        \
         unsigned long long now_ = __builtin_amdgcn_s_memtime(); \

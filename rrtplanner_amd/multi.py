@@ -172,6 +172,10 @@ def init_comm(ctx, rank: int, world_size: int, path: str = None):
     """Create the RCCL communicator of `ctx` (an ``_ffi.Context`` on this rank's GPU): collective over all ranks."""
     from . import _ffi
 
+    alt = os.environ.get("RRT_RCCL_LIB")  # a stand-in collective library (ranks that share one GPU: tests/fake_rccl); the default is RCCL
+    if alt and not getattr(init_comm, "_lib_chosen", False):
+        _ffi.comm_use_library(alt)
+        init_comm._lib_chosen = True
     uid = exchange_unique_id(rank, world_size, _ffi.comm_unique_id, path=path)
     try:
         ctx.comm_init(rank, world_size, uid)

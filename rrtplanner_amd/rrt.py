@@ -12,7 +12,9 @@ There is no CPU fallback for ``plan()``: without the HIP library or a GPU it rai
 Tie policy: nearest node / goal connection pick the lowest index among
 equal distance / cost (== a stable argsort in rrt.py:154 and :317).
 """
+import itertools
 import math
+from collections.abc import Mapping
 from typing import List, Tuple
 
 import networkx as nx
@@ -53,41 +55,260 @@ def _fill_graph_public(T, vgoal, points, parents, vcosts):
             T.add_edge(parent, child, dist=r2norm(points[child] - points[parent]), cost=vcosts[child])
 
 
-def _fill_graph(T, vgoal, points, parents, vcosts):
+def _fill_graph(T, vgoal, points, parents, vcosts, node_dicts=None, edge_dicts=None):
     """Fill the node / adjacency dictionaries of DiGraph `T` like build_graph of the reference (rrt.py:357-369): node order
     [vgoal, 0, 1, ...], one edge per tree link in the order of `parents`, attributes `pt` (int64 row view), `dist` (float),
     `cost` (np.float64).  The dictionaries are written directly (same dict-of-dict layout `add_node` / `add_edge` produce, one
     shared attribute dict per edge in `_succ` and `_pred`), ~3x faster than 100 000 add_node / add_edge calls;
-    tests/test_host_logic.py compares it with the call-by-call construction."""
+    tests/test_host_logic.py compares it with the call-by-call construction.
+    node_dicts / edge_dicts: attribute dictionaries the array-backed views of a TreeDiGraph have already handed out (by vertex /
+    by child); they become the graph's own, so that whatever a caller wrote into them stays."""
     if not _NX_FAST:
         return _fill_graph_public(T, vgoal, points, parents, vcosts)
     rows = len(points)
     order = [vgoal] + [i for i in range(rows) if i != vgoal] if 0 <= vgoal < rows else [vgoal] + list(range(rows))
-    pts = list(points)  # row views, like `for i, p in enumerate(points)`
     node, succ, pred = T._node, T._succ, T._pred
-    for v in order:
-        node[v] = {"pt": pts[v]}
-        succ[v] = {}
-        pred[v] = {}
+    if node_dicts is None:
+        pts = list(points)  # row views, like `for i, p in enumerate(points)`
+        for v in order:
+            node[v] = {"pt": pts[v]}
+            succ[v] = {}
+            pred[v] = {}
+    else:
+        for v in order:
+            node[v] = node_dicts[v]
+            succ[v] = {}
+            pred[v] = {}
     kids = [c for c, p in parents.items() if p is not None]
     if kids:
         ch = np.asarray(kids, dtype=np.int64)
         pa = np.asarray([parents[c] for c in kids], dtype=np.int64)
-        d = points[ch] - points[pa]
-        dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64)).tolist()
-        for p, c, dd, cc in zip(pa.tolist(), kids, dist, vcosts[ch]):
-            e = {"dist": dd, "cost": cc}
-            succ[p][c] = e
-            pred[c][p] = e
+        if edge_dicts is None:
+            for p, c, e in zip(pa.tolist(), kids, _edge_attr_dicts(points, pa, ch, vcosts)):
+                succ[p][c] = e
+                pred[c][p] = e
+        else:
+            for p, c in zip(pa.tolist(), kids):
+                e = edge_dicts[c]
+                succ[p][c] = e
+                pred[c][p] = e
+
+
+def _edge_attr_dicts(points, pa, ch, vcosts):
+    """{"dist": float, "cost": np.float64} of the edges pa[k] -> ch[k] (rrt.py:366-369)"""
+    d = points[ch] - points[pa]
+    dist = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float64)).tolist()
+    return [{"dist": dd, "cost": cc} for dd, cc in zip(dist, vcosts[ch])]
+
+
+class _ArrayNodeView(Mapping):
+    """`T.nodes` of a TreeDiGraph that still only holds arrays: order [vgoal, 0, 1, ...], `T.nodes[v]` -> {"pt": row v}
+    (rrt.py:357-361).  The attribute dictionaries are made once and become the graph's own when it is materialised; whatever this
+    class does not serve itself (set algebra, data="pt", ...) goes to networkx's NodeView of the materialised graph, and so does
+    every call once the graph has been materialised (a view somebody kept)."""
+
+    __slots__ = ("_g", "_nd", "_rows", "_vgoal")
+
+    def __init__(self, g):
+        self._g = g
+        self._nd = None  # attribute dictionaries by vertex, made on first use
+        self._vgoal, points = g.__dict__["_lazy"][0], g.__dict__["_lazy"][1]
+        self._rows = len(points)
+
+    def _real(self):
+        return nx.reportviews.NodeView(self._g)  # (reads g._node: materialises)
+
+    def _stale(self):
+        return self._g.__dict__["_lazy"] is None
+
+    def __len__(self):
+        return len(self._real()) if self._stale() else self._rows
+
+    def __iter__(self):
+        if self._stale():
+            return iter(self._real())
+        vgoal, rows = self._vgoal, self._rows
+        return itertools.chain((vgoal,), range(vgoal), range(vgoal + 1, rows))
+
+    def __contains__(self, v):
+        if self._stale():
+            return v in self._real()
+        try:
+            return 0 <= v < self._rows and int(v) == v
+        except (TypeError, ValueError):
+            return False
+
+    def __getitem__(self, v):
+        nd = self._nd
+        if nd is None or self._g.__dict__["_lazy"] is None or v.__class__ is not int or v < 0:
+            return self._getitem_slow(v)
+        try:
+            return nd[v]
+        except IndexError:
+            raise KeyError(v) from None
+
+    def _getitem_slow(self, v):
+        if self._stale() or isinstance(v, slice):
+            return self._real()[v]  # (networkx raises its own error for slices)
+        if v not in self:
+            raise KeyError(v)
+        if self._nd is None:
+            self._nd = self._g._arr_node_dicts()
+        return self._nd[int(v)]
+
+    def __call__(self, data=False, default=None):
+        if self._stale() or (data is not False and data is not True):
+            return self._real()(data=data, default=default)
+        return _ArrayNodeDataView(self) if data else self
+
+    def data(self, data=True, default=None):
+        return self(data=data, default=default)
+
+    def __getattr__(self, name):  # anything else NodeView offers
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self._real(), name)
+
+    def __repr__(self):
+        return f"NodeView({tuple(self)})"
+
+
+class _ArrayNodeDataView:
+    __slots__ = ("_v",)
+
+    def __init__(self, v):
+        self._v = v
+
+    def __len__(self):
+        return len(self._v)
+
+    def __iter__(self):
+        v = self._v
+        if v._stale():
+            return iter(v._real()(data=True))
+        nd = v._g._arr_node_dicts()
+        return zip(v, map(nd.__getitem__, v))
+
+    def __contains__(self, item):
+        try:
+            v, d = item
+            return v in self._v and self._v[v] == d
+        except (TypeError, ValueError):
+            return False
+
+    def __getitem__(self, v):
+        return self._v[v]
+
+
+class _ArrayEdgeView:
+    """`T.edges` of a TreeDiGraph that still only holds arrays: the edges parent -> child in networkx's order (by source vertex in
+    node order, then by insertion = child index), `T.edges[u, v]` -> {"dist", "cost"} (rrt.py:363-369), `T.edges(data=True)`.
+    An edge (u, v) exists iff u is v's parent, so lookups need no table.  Everything else goes to networkx's OutEdgeView of the
+    materialised graph, and so does every call once the graph has been materialised."""
+
+    __slots__ = ("_g", "_par", "_ed")
+
+    def __init__(self, g):
+        self._g = g
+        self._par = None  # parent of every live vertex as a list, the edges' attribute dictionaries by child: made on first use
+        self._ed = None
+
+    def _real(self):
+        return nx.reportviews.OutEdgeView(self._g)
+
+    def _stale(self):
+        return self._g.__dict__["_lazy"] is None
+
+    def __len__(self):
+        return len(self._real()) if self._stale() else max(self._g._arr_live() - 1, 0)
+
+    def __iter__(self):
+        if self._stale():
+            return iter(self._real())
+        us, vs = self._g._arr_edge_order()
+        return zip(us, vs)
+
+    def _child_of(self, e):
+        try:
+            u, v = e
+            if self._par is None:
+                self._par = self._g.__dict__["_lazy"][2].tolist()
+            if 1 <= v < len(self._par) and int(v) == v and self._par[int(v)] == u:
+                return int(v)
+        except (TypeError, ValueError):
+            pass
+        return None
+
+    def __contains__(self, e):
+        return (e in self._real()) if self._stale() else self._child_of(e) is not None
+
+    def __getitem__(self, e):
+        if self._g.__dict__["_lazy"] is None or isinstance(e, slice):
+            return self._real()[e]
+        par, ed = self._par, self._ed
+        if ed is not None and e.__class__ is tuple and len(e) == 2:  # fast path: plain ints, as the views' own iteration hands out
+            v = e[1]
+            if v.__class__ is int and 0 < v < len(par) and par[v] == e[0]:
+                return ed[v]
+        c = self._child_of(e)
+        if c is None:
+            raise KeyError(e)
+        if self._ed is None:
+            self._ed = self._g._arr_edge_dicts()
+        return self._ed[c]
+
+    def __call__(self, nbunch=None, data=False, default=None):
+        if self._stale() or nbunch is not None or (data is not False and data is not True):
+            return self._real()(nbunch=nbunch, data=data, default=default)
+        return _ArrayEdgeDataView(self) if data else self
+
+    def data(self, data=True, default=None, nbunch=None):
+        return self(nbunch=nbunch, data=data, default=default)
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self._real(), name)
+
+    def __repr__(self):
+        return f"OutEdgeView({list(self)})"
+
+
+class _ArrayEdgeDataView:
+    __slots__ = ("_v",)
+
+    def __init__(self, v):
+        self._v = v
+
+    def __len__(self):
+        return len(self._v)
+
+    def __iter__(self):
+        v = self._v
+        if v._stale():
+            return iter(v._real()(data=True))
+        us, vs = v._g._arr_edge_order()
+        ed = v._g._arr_edge_dicts()
+        return zip(us, vs, map(ed.__getitem__, vs))
+
+    def __contains__(self, item):
+        try:
+            u, v, d = item
+            return (u, v) in self._v and self._v[u, v] == d
+        except (TypeError, ValueError):
+            return False
 
 
 class TreeDiGraph(nx.DiGraph):
     """The nx.DiGraph that plan() returns, with its dictionaries filled on first use.
 
-    At n = 50 000 building 100 000 Python dictionaries takes four times as long as the whole expansion on the device, and
-    the usual next calls (route2gv, vertices_as_ndarray) only need the parent pointers and the coordinates.  The instance
-    therefore keeps the result arrays and materialises `_node` / `_adj` / `_succ` / `_pred` when anything first touches
-    them; from then on it is an ordinary DiGraph with exactly the content build_graph gives (tests compare both)."""
+    At n = 50 000 building 100 000 Python dictionaries takes several times as long as the whole expansion on the device, and
+    the usual next calls only need the parent pointers and the coordinates.  The instance therefore keeps the result arrays:
+    route2gv / vertices_as_ndarray read them directly, and `T.nodes` / `T.edges` -- what the reference's consumers use
+    (plots.py:27-29, :40-41; anim.py:101-102) -- are array-backed views (`for u, v in T.edges`, `T.edges(data=True)`, `T.nodes[v]["pt"]`,
+    `T.edges[u, v]["cost"]`) that make each attribute dictionary once and never build the adjacency structure.  Anything else
+    (adjacency, mutation, copy, algorithms) first materialises `_node` / `_adj` / `_succ` / `_pred` with exactly the content
+    build_graph gives (tests compare both), reusing the dictionaries already handed out; from then on it is an ordinary DiGraph."""
 
     def __init__(self, incoming_graph_data=None, **attr):
         self.__dict__["_lazy"] = None
@@ -117,7 +338,82 @@ class TreeDiGraph(nx.DiGraph):
             par = parent.tolist()
             for child in range(1, len(par)):
                 parents[child] = par[child]
-            _fill_graph(self, vgoal, points, parents, vcosts)
+            _fill_graph(self, vgoal, points, parents, vcosts, self.__dict__.pop("_arr_nd", None), self.__dict__.pop("_arr_ed", None))
+            for k in ("_arr_eo", "_arr_nv", "_arr_ev"):
+                self.__dict__.pop(k, None)
+
+    def __getstate__(self):  # (the cached views point back at the graph and are remade on demand)
+        return {k: v for k, v in self.__dict__.items() if k not in ("_arr_nv", "_arr_ev")}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    # ---- array-backed views (only while the graph is lazy, and only for the plain tree: subclasses add attributes) ----
+    def _arr_views(self):
+        lazy = self.__dict__.get("_lazy")
+        return type(self) is TreeDiGraph and lazy is not None and 0 <= lazy[0] < len(lazy[1])
+
+    def _arr_vgoal(self):
+        return self.__dict__["_lazy"][0]
+
+    def _arr_rows(self):
+        return len(self.__dict__["_lazy"][1])
+
+    def _arr_live(self):
+        return len(self.__dict__["_lazy"][2])
+
+    def _arr_node_dicts(self):
+        nd = self.__dict__.get("_arr_nd")
+        if nd is None:
+            nd = self.__dict__["_arr_nd"] = [{"pt": p} for p in self.__dict__["_lazy"][1]]  # row views, like build_graph's
+        return nd
+
+    def _arr_edge_dicts(self):
+        """by child vertex (entry 0: the root has no edge)"""
+        ed = self.__dict__.get("_arr_ed")
+        if ed is None:
+            _, points, parent, vcosts = self.__dict__["_lazy"]
+            ch = np.arange(1, len(parent), dtype=np.int64)
+            ed = self.__dict__["_arr_ed"] = [None] + _edge_attr_dicts(points, np.asarray(parent[1:], dtype=np.int64), ch, vcosts)
+        return ed
+
+    def _arr_edge_order(self):
+        """(sources, targets) of all edges in networkx's iteration order: sources in node order [vgoal, 0, 1, ...], the out-edges
+        of one source in insertion order (ascending child)"""
+        eo = self.__dict__.get("_arr_eo")
+        if eo is None:
+            vgoal, _, parent, _ = self.__dict__["_lazy"]
+            pa = np.asarray(parent[1:], dtype=np.int64)
+            rank = np.where(pa == vgoal, 0, np.where(pa < vgoal, pa + 1, pa))
+            o = np.argsort(rank * len(parent) + np.arange(len(pa)))  # (unique keys: any sort is the stable sort by rank)
+            eo = self.__dict__["_arr_eo"] = (pa[o].tolist(), (o + 1).tolist())
+        return eo
+
+    @property
+    def nodes(self):
+        d = self.__dict__
+        if d.get("_lazy") is None:
+            return nx.reportviews.NodeView(self)
+        v = d.get("_arr_nv")
+        if v is None:
+            if not self._arr_views():
+                return nx.reportviews.NodeView(self)
+            v = d["_arr_nv"] = _ArrayNodeView(self)
+        return v
+
+    @property
+    def edges(self):
+        d = self.__dict__
+        if d.get("_lazy") is None:
+            return nx.reportviews.OutEdgeView(self)
+        v = d.get("_arr_ev")
+        if v is None:
+            if not self._arr_views():
+                return nx.reportviews.OutEdgeView(self)
+            v = d["_arr_ev"] = _ArrayEdgeView(self)
+        return v
+
+    out_edges = edges
 
     def root_path(self, gv):
         """[0, ..., gv] from the parent array while the graph is still lazy, else None"""

@@ -6,6 +6,7 @@
   2. the oracle's sequential loop (oracle/dubins_oracle.c) for the properties that define the planner;
   3. the HIP kernel bit for bit against that oracle (GPU)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -194,6 +195,57 @@ def test_planner_classes_on_the_oracle_stand_in():
     assert s.shape == (3,) and og[s[0], s[1]] == 0 and 0 <= s[2] < 32
 
 
+def _assert_audit_clean(a, star):
+    """What oracle/dubins_ref.c's second opinion must say about a tree (its head comment): every accept / reject and every
+    chosen parent either equal to its own, or within the stated tolerance / ambiguity -- never plainly different."""
+    assert a["nearest_mismatch"] == 0 and a["accept_mismatch"] == 0, a
+    assert a["parent_wrong"] == 0 and a["parent_blocked"] == 0 and a["cost_mismatch"] == 0, a
+    assert a["max_cost_err"] < 1e-8, a
+    assert a["parent_is_argmin"] + a["parent_within_tol"] == a["n_accepted"], a
+    # the tolerance classes are the exception, not the rule
+    assert a["parent_within_tol"] <= max(3, a["n_accepted"] // 1000) and a["accept_ambiguous"] + a["parent_blocked_ambiguous"] <= max(3, a["n_accepted"] // 1000), a
+
+
+def test_independent_reference_words_agree_with_the_shared_header():
+    """dubins_ref.c (libm, textbook closed forms, no shared header) against include/rrt_dubins.h through the oracle, on random
+    pose pairs: same word, lengths and segments to 1e-9."""
+    rng = np.random.default_rng(3)
+    for _ in range(4000):
+        x0, y0, x1, y1 = rng.uniform(0, 200, 4)
+        th0, th1 = 2 * math.pi * rng.integers(0, 64, 2) / 64
+        rho = float(rng.choice([2.0, 6.0, 8.0, 25.0]))
+        a, b = oracle.dubref_shortest(x0, y0, th0, x1, y1, th1, rho), oracle.dub_shortest(x0, y0, th0, x1, y1, th1, rho)
+        assert abs(a[3] - b[3]) < 1e-9 * (1 + b[3])
+        if a[4] == b[4]:
+            assert np.allclose(a[:3], b[:3], atol=1e-8)
+        else:  # two words of (numerically) the same length
+            assert abs(a[3] - b[3]) < 1e-9
+
+
+@pytest.mark.parametrize("star,grid,n,rr,rho,seed", [(0, 300, 4000, None, 6.0, 0), (1, 300, 4000, 40, 6.0, 0), (1, 128, 1500, 20, 25.0, 6), (1, 64, 2500, 12, 2.0, 2)])
+def test_independent_audit_of_the_oracles_tree(star, grid, n, rr, rho, seed):
+    """the oracle and the kernel share the geometry header, so their equality cannot see a wrong formula in it.
+    oracle/dubins_ref.c does not include it; its audit recomputes every accept / reject and every choose-parent decision behind
+    the oracle's tree with libm arithmetic."""
+    og, og8, xs, xg, samples, heads = _dub_query(grid, n, seed)
+    r2 = hostprep.radius_threshold(rr) if star else 0
+    st, r = oracle.dubins_plan(og8, n, star, xs, xg, samples, heads, r2_rewire=r2, rho=rho, nh=64)
+    a = oracle.dubins_audit(og8, n, star, samples, heads, r.pts, r.head, r.vcost, r.parent, r.j, r2_rewire=r2, rho=rho, nh=64)
+    assert a["n_accepted"] == r.j - 1
+    _assert_audit_clean(a, star)
+    # and the audit is not blind: a tree with one wrong parent / one wrong cost is caught
+    if star and r.j > 50:
+        bad = r.parent.copy()
+        k = int(np.argmax(r.parent[1:r.j] != np.asarray(r.nearest_log)[np.flatnonzero(r.accept_log)][: r.j - 1])) + 1  # a vertex whose parent is not its nearest
+        bad[k] = 0 if r.parent[k] != 0 else 1
+        b = oracle.dubins_audit(og8, n, star, samples, heads, r.pts, r.head, r.vcost, bad, r.j, r2_rewire=r2, rho=rho, nh=64)
+        assert b["parent_wrong"] + b["cost_mismatch"] + b["parent_blocked"] + b["nearest_mismatch"] >= 1
+        cost = r.vcost.copy()
+        cost[r.j // 2] += 1e-6
+        c = oracle.dubins_audit(og8, n, star, samples, heads, r.pts, r.head, cost, r.parent, r.j, r2_rewire=r2, rho=rho, nh=64)
+        assert c["cost_mismatch"] >= 1
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 def _device_vs_oracle_dubins(ctx, og8, star, n, xs, xg, samples, heads, rr, rho, nh=64, serial=False, counters=False):
     """serial = False: the 16-samples-per-round kernel (rrt_dubins_block.h, the default); True: the one-sample-per-iteration
@@ -255,6 +307,20 @@ def test_config5_full_size_equals_the_oracle(gpu_ctx):
     assert 0 < res.n_words < ro.n_dubins // 2  # the oracle's walk prices every near-set entry; the kernel one per lane of a pass, up to 64
     _check_dubins_tree(og8, res, cfg["rho"], cfg["nh"], xs)
     assert _independent_collision_witness(og8, res, samples, heads, cfg["rho"], cfg["nh"], count=400) > 50
+    # every accept / reject and every chosen parent of the DEVICE's tree recomputed by oracle/dubins_ref.c (libm,
+    # no shared header) at the config's full size; the counts go to profiles/ via tools/gpu_round.sh
+    a = oracle.dubins_audit(og8, n, 1, samples, heads, res.pts, res.head, res.vcost, res.parent, res.j, r2_rewire=hostprep.radius_threshold(cfg["r_rewire"]),
+                            rho=cfg["rho"], nh=cfg["nh"])
+    print("config 5 independent audit:", a)
+    out = os.environ.get("RRT_AUDIT_OUT")
+    if out:
+        import json
+
+        with open(out, "w") as f:
+            json.dump({"workload": "BASELINE.json configs[4], query 0 (bench.py --config 5), the DEVICE's tree", "audit": a,
+                       "by": "oracle/dubins_ref.c (libm, textbook words, own sweep; does not include include/rrt_dubins.h)"}, f, indent=1)
+    assert a["n_accepted"] == res.j - 1
+    _assert_audit_clean(a, 1)
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 PMC passes of bench.py (tools/gpu_round.sh pmc) -> profiles/r03_traffic.json and profiles/r03_sq_counters.json,
+"""rocprofv3 PMC passes of bench.py (tools/gpu_round.sh pmc) -> profiles/r04_traffic.json and profiles/r04_sq_counters.json,
 which bench.py reports as roofline.measured / roofline.bound_observed when workload and kernel variant match.
 
     python3 tools/pmc_to_json.py gpurun_out/r03 "2 1" "3 1" "4 64" ...      (specs: "CONFIG QUERIES")
@@ -42,7 +42,8 @@ def main(argv):
             continue
         cfg = line["config"]
         team = cfg["cus_per_query"] - (1 if cfg["pipelined"] else 0)
-        key = dict(config=int(c), queries_per_gpu=int(q), n=cfg["n"], team=team, pipelined=bool(cfg["pipelined"]), kernel=line["roofline"]["kernel"])
+        key = dict(config=int(c), queries_per_gpu=int(q), n=cfg["n"], team=team, pipelined=bool(cfg["pipelined"]), kernel=line["roofline"]["kernel"],
+                   build_sha256=(line.get("build") or {}).get("lib_sha256"))  # the binary the pass measured (bench.py reports a pass only on the same build)
         f = mean_counters(base + "FETCH_SIZE", ("FETCH_SIZE",))["FETCH_SIZE"]
         w = mean_counters(base + "WRITE_SIZE", ("WRITE_SIZE",))["WRITE_SIZE"]
         if f is not None and w is not None:
@@ -55,9 +56,9 @@ def main(argv):
             wait, issue, valu = s["SQ_WAIT_ANY"] / wc, s["SQ_ACTIVE_INST_ANY"] / wc, s["SQ_ACTIVE_INST_VALU"] / wc
             kind = "latency (waves wait on s_waitcnt / barriers / hand-offs most of their cycles)" if wait > 0.6 and issue < 0.3 else "instruction issue"
             sq.append(dict(key, kind=kind, waves_waiting_frac=wait, waves_issuing_frac=issue, valu_busy_frac=valu, counters=s,
-                           source="profiles/r03_sq_counters.json (rocprofv3 --pmc " + " ".join(SQ) + ", an earlier run of this workload)"))
-    json.dump({"entries": traffic}, open("profiles/r03_traffic.json", "w"), indent=1)
-    json.dump({"entries": sq}, open("profiles/r03_sq_counters.json", "w"), indent=1)
+                           source="profiles/r04_sq_counters.json (rocprofv3 --pmc " + " ".join(SQ) + ", an earlier run of this workload)"))
+    json.dump({"entries": traffic}, open("profiles/r04_traffic.json", "w"), indent=1)
+    json.dump({"entries": sq}, open("profiles/r04_sq_counters.json", "w"), indent=1)
     for e in traffic:
         print("traffic", e["config"], e["queries_per_gpu"], e["team"], e["pipelined"], e["hbm_bytes_per_launch"])
     for e in sq:

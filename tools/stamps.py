@@ -47,8 +47,9 @@ if os.environ.get("RRT_STAMPS_PIPE"):
     print("committer cyc/block [after the end-of-block barrier, part A, rounds: re-resolutions + barriers, ordered loop, publish, "
           "wave-0 re-resolutions without near-set redo, samples in rounds, loop top to part A, rounds: lists between them, store pass]:",
           [round(x / nblk, 1) for x in w[:10]])
-    print("committer wave-0 resolves: with near-set redo: %d x %.0f cyc; others: %d x %.0f cyc; rounds/block %.2f" % (w[11], w[10] / max(w[11], 1), w[5], w[12] / max(w[5], 1), w[13] / nblk))
-    print("committer: prefetch by wave 1 %.0f cyc/block; wave 0 at the end-of-block barrier %.0f cyc/block" % (w[14] / nblk, w[15] / nblk))
+    print("committer wave-0 resolves: with near-set redo: %d x %.0f cyc; others: %d x %.0f cyc; rounds/block %.2f" % (w[11], w[10] / max(w[11], 1), w[5], w[12] / max(w[5], 1), (w[13] & 0xffffffff) / nblk))
+    print("committer: samples settled by their own lanes (no round): %.2f per block" % ((w[13] >> 32) / nblk))
+    print("committer: fetch of the next block's records %.0f cyc/block, %.0f of them waiting for the workers' flags; wave 0 at the end-of-block barrier %.0f cyc/block" % ((w[14] & 0xffffffff) / nblk, (w[14] >> 32) / nblk, w[15] / nblk))
     print("worker 1  cyc/block [resolve, hand over, go wait, take]:", [round(x / nblk, 1) for x in w[16:20]])
 if os.environ.get("RRT_STAMPS_RAW"):
     print("raw wcyc[0:16]:", list(w[:16]))
