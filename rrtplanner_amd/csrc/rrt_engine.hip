@@ -180,7 +180,9 @@ static hipError_t wait_stream_spin(hipStream_t stream, double spin_ms = 100.0) {
         if (e != hipErrorNotReady) return e;
         if ((it & 1023u) == 1023u && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > spin_ms)
             return hipStreamSynchronize(stream);
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
     }
 }
 
@@ -406,6 +408,11 @@ extern "C" int rrt_select_frame(rrt_ctx *ctx, int32_t frame) {
 #ifndef RRT_CELL_DIV_PIPE
 #define RRT_CELL_DIV_PIPE 4.0  // ... for a query that the one-CU pipeline runs (rrt_pipe.h: its streams leave out the cells beyond the radius,
                                // and a step costs them the same however many cells begin in it).  Measured: profiles/r03_experiments.md
+                               // The divisor is fixed when the query is SET (rrt_batch_set_query: team == 1 and not Informed); the kernel is
+                               // picked at LAUNCH.  A team batch that the CU registry shrank to one CU per query therefore runs the pipeline
+                               // on the coarser cells, and a continuation (block kernel) may run on the finer ones.  Both kernels derive
+                               // the cells they stream from the radius and cell_shift, so results are the same; only the tuning differs,
+                               // and timings of such launches are not comparable with the tuned shape (rrt_batch_team_info says which ran).
 #endif
 static void cell_geometry(int W, int H, int64_t r2, int n, double div, int &shift, int &ncx, int &ncy, int &cap) {
     double r = std::sqrt((double)(r2 < 1 ? 1 : r2));
@@ -1021,13 +1028,16 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
 #endif
     // A team whose members were not resident together stops at a block boundary with a consistent tree (ST_TEAM_FAIL, a
     // bounded wait expired).  Teams are only an optimisation: the batch continues from there with one CU per query.
+    // (Only such launches are continued: the Dubins pipeline's stall exit also says ST_TEAM_FAIL, and there the status stays so that
+    // rrt_batch_get_result reports RRT_E_HIP instead of "has not run".)
     bool team_fail = false;
+    const bool can_continue = b->use_block && (b->team > 1 || b->last_pipe1);
     for (auto &d : b->h_desc)
-        if (d.status == ST_TEAM_FAIL) {
+        if (d.status == ST_TEAM_FAIL && can_continue) {
             d.status = ST_RUNNING;
             team_fail = true;
         }
-    if (team_fail && (b->team > 1 || b->last_pipe1)) {
+    if (team_fail) {
         float ms0 = 0.f;
         (void)hipEventElapsedTime(&ms0, b->ev0, b->ev1);  // the launch that timed out counts in rrt_batch_elapsed_ms
         b->team_fallbacks += 1;
@@ -1150,8 +1160,9 @@ extern "C" int rrt_batch_get_result(rrt_batch *b, int32_t q, rrt_result *out) {
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (d.status == ST_TEAM_FAIL)
-        return fail(ctx, RRT_E_HIP, "query %d: the %d workgroups of its team were not resident together (a hand-off timed out); "
-                    "use RRT_FLAG_NOTEAM when other kernels share the device", q, b->team);
+        return fail(ctx, RRT_E_HIP, b->dub_block ? "query %d: the Dubins pipeline stalled (a bounded wait inside the kernel expired at sample %d); the tree up to there is consistent"
+                                                 : "query %d: the workgroups of its team (%d) were not resident together (a hand-off timed out); "
+                                                   "use RRT_FLAG_NOTEAM when other kernels share the device", q, b->dub_block ? d.i : b->team);
     return d.status < 0 ? d.status : RRT_OK;
 }
 
@@ -1446,6 +1457,7 @@ extern "C" int rrt_plan_batch(rrt_ctx *ctx, int32_t Q, const rrt_query *queries,
 struct rrt_tree {
     rrt_ctx *ctx = nullptr;
     int32_t cap = 0, j = 0;
+    int32_t W = 0, H = 0;  // the grid the vertices were checked against (first append after create / reset); a query on another shape is refused
     uint32_t *d_nodes = nullptr;
     uint32_t *h_nodes = nullptr;  // page-locked mirror: an append is one 4-byte copy in stream order
     int32_t *d_out = nullptr;     // [2 + cap]
@@ -1495,6 +1507,7 @@ extern "C" int rrt_tree_reset(rrt_tree *t) {
     HIPCHK(t->ctx, hipSetDevice(t->ctx->device));
     HIPCHK(t->ctx, hipStreamSynchronize(t->ctx->stream));  // an append still in flight reads the mirror
     t->j = 0;
+    t->W = t->H = 0;
     return RRT_OK;
 }
 
@@ -1502,7 +1515,16 @@ extern "C" int rrt_tree_append(rrt_tree *t, int32_t x, int32_t y, int32_t *index
     if (!t) return fail(nullptr, RRT_E_ARG, "rrt_tree_append: NULL");
     rrt_ctx *ctx = t->ctx;
     if (t->j >= t->cap) return fail(ctx, RRT_E_ARG, "rrt_tree_append: the tree holds its %d vertices", t->cap);
-    if (x < 0 || x >= RRT_GRID_MAX || y < 0 || y >= RRT_GRID_MAX) return fail(ctx, RRT_E_ARG, "rrt_tree_append: (%d, %d) outside [0, %d)^2", x, y, RRT_GRID_MAX);
+    // every stored vertex later starts a line-of-sight walk over the context's grid (tree_query_kernel): it must lie inside THAT grid
+    if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_tree_append: no grid");
+    if (t->j == 0) {
+        t->W = ctx->W;
+        t->H = ctx->H;
+    } else if (t->W != ctx->W || t->H != ctx->H) {
+        return fail(ctx, RRT_E_ARG, "rrt_tree_append: the grid changed shape (%dx%d -> %dx%d) since the tree's first vertex: rrt_tree_reset first", t->W, t->H, ctx->W, ctx->H);
+    }
+    if (x < 0 || x >= ctx->W || y < 0 || y >= ctx->H || x >= RRT_GRID_MAX || y >= RRT_GRID_MAX)
+        return fail(ctx, RRT_E_ARG, "rrt_tree_append: (%d, %d) outside the %dx%d grid", x, y, ctx->W, ctx->H);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     t->h_nodes[t->j] = ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16);
     HIPCHK(ctx, hipMemcpyAsync(t->d_nodes + t->j, t->h_nodes + t->j, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1518,6 +1540,8 @@ extern "C" int rrt_tree_query(rrt_tree *t, int32_t x, int32_t y, int64_t r2, int
     rrt_ctx *ctx = t->ctx;
     if (!ctx->og) return fail(ctx, RRT_E_NOGRID, "rrt_tree_query: no grid");
     if (t->j < 1) return fail(ctx, RRT_E_ARG, "rrt_tree_query: the tree is empty");
+    if (t->W != ctx->W || t->H != ctx->H)
+        return fail(ctx, RRT_E_ARG, "rrt_tree_query: the tree's vertices were checked against a %dx%d grid, the context now holds %dx%d", t->W, t->H, ctx->W, ctx->H);
     if (x < 0 || x >= ctx->W || y < 0 || y >= ctx->H) return fail(ctx, RRT_E_ARG, "rrt_tree_query: (%d, %d) outside the %dx%d grid", x, y, ctx->W, ctx->H);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int dcap = cap < t->cap ? cap : t->cap;

@@ -1046,6 +1046,35 @@ def test_custom_costfn_runs_on_the_device_primitives():
         depth[v] = d["cost"]
 
 
+def test_device_tree_vertices_are_checked_against_the_grid():
+    """every vertex of a host-driven planner's tree later starts a line-of-sight walk over the context's grid, so
+    rrt_tree_append refuses a vertex outside THAT grid (not just outside the 15-bit range), and a query after the grid changed
+    shape is refused until the tree is reset."""
+    ctx = _ffi.Context(0)
+    tr = _ffi.DeviceTree(ctx, 16)
+    with pytest.raises(_ffi.RRTError) as e:
+        tr.append(1, 1)  # no grid yet
+    assert e.value.code == _ffi.RRT_E_NOGRID
+    ctx.set_grid(np.zeros((40, 30), dtype=np.uint8))
+    assert tr.append(5, 5) == 0 and tr.append(39, 29) == 1
+    for bad in ((40, 5), (5, 30), (-1, 0), (1000, 1000)):
+        with pytest.raises(_ffi.RRTError) as e:
+            tr.append(*bad)
+        assert e.value.code == _ffi.RRT_E_ARG
+    nn, idx, los, _ = tr.query(6, 6, 10 ** 6)
+    assert nn == 0 and idx.tolist() == [0, 1] and los
+    ctx.set_grid(np.zeros((20, 20), dtype=np.uint8))  # vertex 1 = (39, 29) now lies outside
+    with pytest.raises(_ffi.RRTError) as e:
+        tr.query(6, 6, 100)
+    assert e.value.code == _ffi.RRT_E_ARG
+    with pytest.raises(_ffi.RRTError):
+        tr.append(3, 3)
+    tr.reset()
+    assert tr.append(3, 3) == 0 and tr.query(4, 4, 100)[0] == 0
+    tr.close()
+    ctx.close()
+
+
 def test_context_close_takes_its_batches_along():
     """Closing a context first closes the batches created on it (they hold a pointer to it); closing them again is harmless."""
     ctx = _ffi.Context(0)

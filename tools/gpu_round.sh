@@ -21,6 +21,11 @@ d=json.load(open("$O/bench_driver_cmd.json"))
 print("ms_per_step %.3f kernel_ms %.3f host_gap_ms %.3f value %.4g"%(d["ms_per_step"], d["roofline"]["kernel_ms"], d["host_gap_ms"], d["value"]))
 PY
     ;;
+total512)
+    # BASELINE configs[3] as the job it names -- 512 queries -- on ONE GPU (the denominator of the 8-GPU strong-scaling claim)
+    python3 $R/bench.py --config 4 --total-queries 512 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config4_total512_n1.json 2> $O/bench_config4_total512_n1.err; echo "total512 rc=$?"; tail -n 2 $O/bench_config4_total512_n1.err
+    python3 -c "
+import json; d=json.load(open('$O/bench_config4_total512_n1.json')); print('512 queries on one GPU: ms_per_step %.2f kernel_ms %.2f value %.4g cus/query %s kernel %s' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['value'], d['config']['cus_per_query'], d['roofline']['kernel']))" ;;
 gap)
     python3 $R/tools/step_gap.py --steps 20 > $O/step_gap.txt 2>&1; echo "gap rc=$?"; cat $O/step_gap.txt
     python3 $R/tools/step_gap.py --steps 20 --config 4 >> $O/step_gap.txt 2>&1; tail -n 9 $O/step_gap.txt ;;
