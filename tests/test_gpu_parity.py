@@ -883,7 +883,7 @@ def test_every_team_size_gives_the_same_trees_every_time(gpu_ctx):
 def test_maximum_capacity_on_the_largest_grid(gpu_ctx):
     """The limits of this path: n = 262143 samples on a 2048 x 2048 grid, RRT*, default team -- node indices use
     all 18 bits, the scan key all 64 chunk tags, squared distances all 23 bits.  Whole tree equal to the oracle's; one sample
-    more is refused.  (tools/big_case.py runs the other planners and one CU at this size.)"""
+    more is refused.  (tools/archive/big_case.py runs the other planners and one CU at this size.)"""
     og = perlin_occupancygrid(2048, 2048, seed=3)
     og8 = oracle.og_u8(og)
     gpu_ctx.set_grid(og8)

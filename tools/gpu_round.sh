@@ -6,6 +6,9 @@ O=$R/gpurun_out/r04
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
+# every summary that goes to profiles/ names the binary it measured (bench.py reports a counter pass only on the same build)
+BUILD=$(python3 -c "import hashlib;print(hashlib.sha256(open('$R/rrtplanner_amd/librrt_hip.so','rb').read()).hexdigest()[:16])")
+echo "librrt_hip.so sha256[:16] = $BUILD" > $O/BUILD_ID.txt
 for what in "$@"; do
 case $what in
 smoke)
@@ -73,12 +76,24 @@ prof)
     for c in 2 3 4 5; do
         rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c$c -- python3 $R/bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline --no-batched > $O/prof_c$c.json 2> $O/prof_c$c.err
         echo "prof c$c rc=$?"
-        f=$(ls -t $O/prof_c$c/*/*kernel_stats.csv 2>/dev/null | head -n 1); [ -n "$f" ] && cp $f $O/config${c}_kernel_stats.csv
+        f=$(ls -t $O/prof_c$c/*/*kernel_stats.csv 2>/dev/null | head -n 1)
+        [ -n "$f" ] && (echo "# build $BUILD (sha256[:16] of librrt_hip.so); rocprofv3 --kernel-trace --stats -- bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline --no-batched"; cat $f) > $O/config${c}_kernel_stats.csv
     done
     # the one-CU-per-query pipeline (rrt_pipe_kernel): 256 x config 2
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2_q256 -- python3 $R/bench.py --queries 256 --steps 5 --warmup 1 --no-cpu-baseline --no-batched > $O/prof_c2_q256.json 2> $O/prof_c2_q256.err
     echo "prof c2 q256 rc=$?"
-    f=$(ls -t $O/prof_c2_q256/*/*kernel_stats.csv 2>/dev/null | head -n 1); [ -n "$f" ] && cp $f $O/config2_q256_kernel_stats.csv ;;
+    f=$(ls -t $O/prof_c2_q256/*/*kernel_stats.csv 2>/dev/null | head -n 1)
+    [ -n "$f" ] && (echo "# build $BUILD (sha256[:16] of librrt_hip.so); rocprofv3 --kernel-trace --stats -- bench.py --queries 256 --steps 5 --warmup 1 --no-cpu-baseline --no-batched"; cat $f) > $O/config2_q256_kernel_stats.csv ;;
+stamps)
+    # the diagnostic build's cycle stamps (never the product's run times): all sixteen per block, and the four-stamp form whose
+    # balance of the ring is close to the product build's
+    (cd $R && make -C rrtplanner_amd/csrc -j16 stamps > $O/stamps_build.log 2>&1 && make -C rrtplanner_amd/csrc -j16 exp EXP="-DRRT_STAMPS -DRRT_STAMPS_LIGHT=0x8016" NAME=light >> $O/stamps_build.log 2>&1); echo "stamps builds rc=$?"
+    (echo "# tools/stamps.py, diagnostic builds of the sources whose product build is $BUILD (run times of these builds are not the product's)"
+     echo "## config 2 default (64+1), all stamps"; cd $R && RRT_STAMPS_PIPE=1 RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so timeout -k 10 200 python3 tools/stamps.py
+     echo "## config 4 share: 64 queries n=20000 default team (3+1 pipelined), all stamps"; RRT_STAMPS_PIPE=1 RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so timeout -k 10 200 python3 tools/stamps.py --n 20000 --queries 64
+     echo "## config 2 default (64+1), LIGHT stamps (mask 0x8016): committer wcyc[1] = block start .. part A done, [2] = .. lists + rounds done, [4] = .. published, [15] = .. past the end-of-block barrier; [14] low half = fetch of the next block's records, high half = its wait for the workers' flags; worker 1 wcyc[16+1] = take + resolve + hand over, [16+2] = go wait (cycles over the whole run: divide by 782 blocks)"
+     RRT_STAMPS_RAW=1 RRT_HIP_LIB=rrtplanner_amd/librrt_hip_exp_light.so timeout -k 10 200 python3 tools/stamps.py | grep -E "kernel|raw") > $O/stamps.txt 2>&1
+    grep -E "^##|kernel|committer" $O/stamps.txt | cut -c1-200 ;;
 pmc)
     SPECS=("2 1" "3 1" "4 64" "2 8" "2 256" "5 256")
     for spec in "${SPECS[@]}"; do
