@@ -242,7 +242,9 @@ struct GSlot {
     uint32_t i1, i2;
     uint32_t hits, nlist; // after stream_cells: |within| of the share, parked entries; after consume_list: nlist = open entries
     uint32_t nn_d2, nn_idx;  // after stream_cells: the nearest of the share's hits (NONE: no hit)
-    uint32_t pad[2];
+    uint32_t pad[2];      // (consume: pad[0] = the share's amin)
+    uint32_t x1, x2;      // coordinates of the two cheapest (the records hold them: no look-up in front of their lines of sight)
+    uint32_t nn_xy, nn_vlo, nn_vhi;  // coordinates and vcost of that nearest hit (its record's)
 };
 struct GCtl {
     double lbc;
@@ -581,8 +583,35 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     // nn_d2 / nn_idx: the nearest of the hits (smallest d2, lowest index among equals; NONE / NONE without a hit).  A hit lies
     // within r_rewire, and every node outside the streamed cells is farther than that: if there is a hit, this IS the nearest
     // node of the whole snapshot (near()[0], rrt.py:150-155) -- the brute-force scan is only needed when the ball is empty.
+    // Top2::wave_reduce with the entries' coordinates riding along: lane values (tt, fx1, fx2) -> the wave's two cheapest in tt and
+    // their coordinates in (ox1, ox2).  (An index names one record, so one lane holds each winner.)
+    auto top2_reduce_xy = [&](Top2 &tt, uint32_t fx1, uint32_t fx2, uint32_t &ox1, uint32_t &ox2) {
+        double bc = tt.c1;
+        uint32_t bi = tt.i1;
+        wave_min_f64_idx(bc, bi);
+        const bool own = tt.i1 != NONE && tt.c1 == bc && tt.i1 == bi;
+        double sc = own ? tt.c2 : tt.c1;
+        uint32_t si = own ? tt.i2 : tt.i1;
+        const uint32_t sxy = own ? fx2 : fx1;
+        const double sc_l = sc;
+        const uint32_t si_l = si;
+        wave_min_f64_idx(sc, si);
+        const u64 m1 = __ballot(own), m2 = __ballot(si_l != NONE && sc_l == sc && si_l == si);
+        ox1 = m1 ? (uint32_t)__builtin_amdgcn_readlane((int)fx1, (int)__builtin_ctzll(m1)) : 0u;
+        ox2 = m2 ? (uint32_t)__builtin_amdgcn_readlane((int)sxy, (int)__builtin_ctzll(m2)) : 0u;
+        tt.c1 = bc;
+        tt.i1 = bi;
+        tt.c2 = sc;
+        tt.i2 = si;
+    };
+    // sx: what the stream also knows about its answers from the records themselves (wave-uniform after the call): the coordinates of
+    // the two cheapest entries, the coordinates and vcost of the nearest hit
+    struct StreamExtra {
+        uint32_t x1, x2, nn_xy, nn_vlo, nn_vhi;
+    } sx = {0u, 0u, 0u, 0u, 0u};
     auto stream_cells = [&](uint32_t X, int j0, bool check_j0, double bound, double lbc, uint32_t lbi, int part, int nparts, Top2 &tt,
                             uint32_t &nnear_part, uint32_t &nlist, uint32_t &nn_d2, uint32_t &nn_idx) {
+        uint32_t fx1 = 0, fx2 = 0, lxy = 0, lvlo = 0, lvhi = 0;  // this lane's: coordinates of its two cheapest, its nearest hit's coordinates and vcost
         const int x = ux(X), y = uy(X);
         const int cx0 = (x - rad < 0 ? 0 : x - rad) >> cshift, cx1 = (x + rad > W - 1 ? W - 1 : x + rad) >> cshift;
         const int cy0 = (y - rad < 0 ? 0 : y - rad) >> cshift, cy1 = (y + rad > H - 1 ? H - 1 : y + rad) >> cshift;
@@ -604,6 +633,9 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (hit && (d2 < ld2 || (d2 == ld2 && rc.y < lidx))) {
                 ld2 = d2;
                 lidx = rc.y;
+                lxy = rc.x;
+                lvlo = rc.z;
+                lvhi = rc.w;
             }
             if (!star) return;  // RRTStandard: the stream only names the nearest node
             // park everything whose vcost alone can be below the bound (the high word of a non-negative f64 is monotone)
@@ -624,7 +656,15 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             if (maybe) {
                 const double cn = V + sqrt_u24(d2);
                 const bool in = cn < bound && !key_lt(cn, rc.y, lbc, lbi);  // rrt.py:518, strict
-                if (in) tt.fold(cn, rc.y);
+                if (in) {
+                    if (key_lt(cn, rc.y, tt.c1, tt.i1)) {
+                        fx2 = fx1;
+                        fx1 = rc.x;
+                    } else if (key_lt(cn, rc.y, tt.c2, tt.i2)) {
+                        fx2 = rc.x;
+                    }
+                    tt.fold(cn, rc.y);
+                }
                 // (m1, m2) <- the two smallest of {m1, m2, cu}, without branches: written as conditional assignments the pair
                 // ends up behind a select of addresses and lives in scratch memory, a store and two loads per priced record
                 const float cu = in ? screen_of(cn) : FINF;
@@ -720,10 +760,17 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             }
         }
         nnear_part = wave_sum_u32(hits);
-        tt.wave_reduce();
+        top2_reduce_xy(tt, fx1, fx2, sx.x1, sx.x2);
         nn_d2 = ld2;
         nn_idx = lidx;
         wave_min_key_idx(nn_d2, nn_idx);
+        {
+            const u64 mn = __ballot(lidx != NONE && ld2 == nn_d2 && lidx == nn_idx);
+            const int ln_ = mn ? (int)__builtin_ctzll(mn) : 0;
+            sx.nn_xy = (uint32_t)__builtin_amdgcn_readlane((int)lxy, ln_);
+            sx.nn_vlo = (uint32_t)__builtin_amdgcn_readlane((int)lvlo, ln_);
+            sx.nn_vhi = (uint32_t)__builtin_amdgcn_readlane((int)lvhi, ln_);
+        }
     };
 
     // Price this wave's parked entries once and compact the ones still open (cost < bound, key >= lower bound) to the front
@@ -1433,6 +1480,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     sl_.nn_d2 = nd2;
                     sl_.nn_idx = nidx;
                     sl_.pad[0] = sl_.pad[1] = 0;
+                    sl_.x1 = sx.x1;
+                    sl_.x2 = sx.x2;
+                    sl_.nn_xy = sx.nn_xy;
+                    sl_.nn_vlo = sx.nn_vlo;
+                    sl_.nn_vhi = sx.nn_vhi;
                     gslot[wave] = sl_;
                 }
                 __syncthreads();
@@ -1498,27 +1550,107 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             double lbc = -1.0;
             uint32_t lbi = 0;
             if (lead && act) {
-                if (grid_nn) {  // the nearest of the shares' hits is the nearest node; an empty ball: this wave scans the nodes
-                    uint32_t gd = NONE, gi = NONE, gh = 0;
+                // (grid_nn) ONE memory round trip for the leader: the shares' slots hold the coordinates and the vcost of the nearest hit
+                // and the coordinates of their two cheapest entries (all from the records the stream read anyway), so the line of sight
+                // from the nearest vertex and those from the group's two cheapest candidates go out together.  (Round 3: the nearest's
+                // cost and coordinates were fetched first, then its line of sight, then the candidates' coordinates, then theirs.)
+                Top2 tt;
+                tt.init();
+                uint32_t tx1 = 0, tx2 = 0;
+                bool overflow = false, tested3 = false, ok1 = false, ok2 = false;
+                int cc1 = 0, cc2 = 0;
+                if (grid_nn) {
+                    uint32_t gd = NONE, gi = NONE, gh = 0, gxy = 0, gvlo = 0, gvhi = 0, fx1 = 0, fx2 = 0;
+                    bool ovf_l = false;
                     if (lane < WPS) {
-                        gd = gslot[sl * WPS + lane].nn_d2;
-                        gi = gslot[sl * WPS + lane].nn_idx;
-                        gh = gslot[sl * WPS + lane].hits;
+                        const GSlot o = gslot[sl * WPS + lane];
+                        gd = o.nn_d2;
+                        gi = o.nn_idx;
+                        gh = o.hits;
+                        gxy = o.nn_xy;
+                        gvlo = o.nn_vlo;
+                        gvhi = o.nn_vhi;
+                        tt.c1 = o.c1;
+                        tt.i1 = o.i1;
+                        tt.c2 = o.c2;
+                        tt.i2 = o.i2;
+                        fx1 = o.x1;
+                        fx2 = o.x2;
+                        ovf_l = o.nlist > clist_cap;
                     }
+                    const uint32_t gd_l = gd, gi_l = gi;
                     wave_min_key_idx(gd, gi);
-                    if (wave_sum_u32(gh) != 0) {
+                    const uint32_t hits_all = wave_sum_u32(gh);
+                    overflow = __ballot(ovf_l) != 0;
+                    if (star) {
+                        top2_reduce_xy(tt, fx1, fx2, tx1, tx2);
+                        nnear += hits_all;
+                    } else {
+                        tt.init();
+                    }
+                    if (hits_all != 0) {  // the nearest of the shares' hits is the nearest node; its record named its place and its cost
                         d2s = gd;
                         vs = gi;
-                    } else {
+                        const u64 mn = __ballot(gi_l != NONE && gd_l == gd && gi_l == gi);
+                        const int ln_ = (int)__builtin_ctzll(mn);
+                        vsxy = (uint32_t)__builtin_amdgcn_readlane((int)gxy, ln_);
+                        Vs = __longlong_as_double((long long)(((u64)(uint32_t)__builtin_amdgcn_readlane((int)gvhi, ln_) << 32) |
+                                                              (uint32_t)__builtin_amdgcn_readlane((int)gvlo, ln_)));
+                    } else {  // an empty ball: this wave scans the nodes
                         wave_scan_nearest(Xk, j0, d2s, vs);
+                        Vs = ld_f64<COH>(&at32(vcost, vs));
+                        vsxy = node_xy(vs);
                     }
-                    Vs = ld_f64<COH>(&at32(vcost, vs));
                     cnear_s = Vs + sqrt_u24(d2s);
                     bm_word = ld_u32<COH>(&at32(bitmap, cell >> 5));
-                    vsxy = node_xy(vs);
-                    lp = los_issue(og, H, vsxy, Xk, lane);
+                    if (star) {
+                        // the cheapest entry at or above the bound, where the two cheapest of the ball tell (see finish_parent)
+                        amin = (tt.i1 == NONE) ? FINF : !(tt.c1 < cnear_s) ? lower_f32(tt.c1) : (tt.i2 == NONE) ? FINF : !(tt.c2 < cnear_s) ? lower_f32(tt.c2) : 0.0f;
+                        if (tt.i2 != NONE && !(tt.c2 < cnear_s)) {
+                            tt.i2 = NONE;
+                            tt.c2 = f64_inf();
+                        }
+                        if (tt.i1 != NONE && !(tt.c1 < cnear_s)) tt.init();
+                    }
+                    if (hits_all != 0 && rad < 64 && !overflow) {  // (every segment shorter than 64 cells: one cell per lane)
+                        const uint32_t a3[3] = {vsxy, tt.i1 != NONE ? tx1 : Xk, tt.i2 != NONE ? tx2 : Xk};
+                        bool ok3[3];
+                        int cells3[3];
+                        los_batch_n<3>(og, H, a3, tt.i2 != NONE ? 3 : (tt.i1 != NONE ? 2 : 1), Xk, lane, ok3, cells3);
+                        free_s = ok3[0];
+                        cells = cells3[0];
+                        ok1 = ok3[1];
+                        cc1 = cells3[1];
+                        ok2 = ok3[2];
+                        cc2 = cells3[2];
+                        tested3 = true;
+                    } else {
+                        lp = los_issue(og, H, vsxy, Xk, lane);
+                    }
+                } else if (star) {  // (the nearest came from phase A: the shares streamed under the bound)
+                    uint32_t hits_l = 0, fx1 = 0, fx2 = 0;
+                    bool ovf_l = false;
+                    if (lane < WPS) {
+                        const GSlot o = gslot[sl * WPS + lane];
+                        tt.c1 = o.c1;
+                        tt.i1 = o.i1;
+                        tt.c2 = o.c2;
+                        tt.i2 = o.i2;
+                        fx1 = o.x1;
+                        fx2 = o.x2;
+                        hits_l = o.hits;
+                        ovf_l = o.nlist > clist_cap;
+                    }
+                    top2_reduce_xy(tt, fx1, fx2, tx1, tx2);
+                    nnear += wave_sum_u32(hits_l);
+                    overflow = __ballot(ovf_l) != 0;
+                    if (tt.i2 != NONE && !(tt.c2 < cnear_s)) {
+                        tt.i2 = NONE;
+                        tt.c2 = f64_inf();
+                    }
+                    if (tt.i1 != NONE && !(tt.c1 < cnear_s)) tt.init();
                 }
-                free_s = los_finish(lp, og, H, vsxy, Xk, lane, cells);
+                if (!tested3) free_s = los_finish(lp, og, H, vsxy, Xk, lane, cells);
                 // earlier samples of this block that could interact once inserted
                 const uint32_t xo = (lane < sidx) ? xq_lds[lane] : Xk;
                 const uint32_t dk = dist2(xo, Xk);
@@ -1541,33 +1673,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 gs2 = __builtin_amdgcn_s_memtime();
 #endif
                 if (star) {
-                    Top2 tt;
-                    tt.init();
-                    bool overflow = false;
-#pragma unroll
-                    for (int pp = 0; pp < WPS; ++pp) {
-                        const GSlot o = gslot[sl * WPS + pp];
-                        if (o.i1 != NONE) tt.fold(o.c1, o.i1);  // (grid_nn: the shares streamed without the bound)
-                        if (o.i2 != NONE) tt.fold(o.c2, o.i2);
-                        nnear += o.hits;
-                        overflow = overflow || o.nlist > clist_cap;
-                    }
-                    // the cheapest entry at or above the bound, where the two cheapest of the ball tell (see finish_parent)
-                    if (grid_nn) amin = (tt.i1 == NONE) ? FINF : !(tt.c1 < cnear_s) ? lower_f32(tt.c1) : (tt.i2 == NONE) ? FINF : !(tt.c2 < cnear_s) ? lower_f32(tt.c2) : 0.0f;
-                    if (tt.i2 != NONE && !(tt.c2 < cnear_s)) {
-                        tt.i2 = NONE;
-                        tt.c2 = f64_inf();
-                    }
-                    if (tt.i1 != NONE && !(tt.c1 < cnear_s)) tt.init();
                     if (overflow) {  // a radius far beyond the cell size: this wave resolves the sample on its own
                         nnear = 0;
                         amin = 0.0f;
                         snapshot_parent(Xk, j0, false, cnear_s, pc, pi, nnear, ntests, tcells);
                     } else if (tt.i1 != NONE) {
                         // the two cheapest, both lines of sight in flight together (rrt.py:519); the second counts only if needed
-                        bool ok1, ok2;
-                        int cc1, cc2;
-                        los_wave2(og, H, node_xy(tt.i1), tt.i2 != NONE ? node_xy(tt.i2) : Xk, tt.i2 != NONE, Xk, lane, ok1, cc1, ok2, cc2);
+                        if (!tested3) los_wave2(og, H, tx1, tt.i2 != NONE ? tx2 : Xk, tt.i2 != NONE, Xk, lane, ok1, cc1, ok2, cc2);
                         ntests += 1;
                         tcells += (uint32_t)cc1;
                         if (ok1) {
