@@ -473,10 +473,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
 #endif
 
 #if defined(RRT_STAMPS)
-    // wall-clock stamp of event ev of block ep (blocks 300 .. 331 of query 0's run), by one lane
+    // wall-clock stamp of event ev of block ep (32 blocks of the run from RRT_TS_BASE on), by one lane
+#ifndef RRT_TS_BASE
+#define RRT_TS_BASE 300
+#endif
 #define TSMARK(ep, ev)                                                                                          \
     do {                                                                                                        \
-        if ((int)(ep) >= 300 && (int)(ep) < 332 && lane == 0) D->ts[((int)(ep) - 300) * 16 + (ev)] = wall_clock64(); \
+        if ((int)(ep) >= RRT_TS_BASE && (int)(ep) < RRT_TS_BASE + 32 && lane == 0) D->ts[((int)(ep) - RRT_TS_BASE) * 16 + (ev)] = wall_clock64(); \
     } while (0)
 #else
 #define TSMARK(ep, ev) \

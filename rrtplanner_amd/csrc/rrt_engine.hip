@@ -1020,7 +1020,7 @@ extern "C" int rrt_batch_sync(rrt_batch *b) {
             fprintf(stderr, "\n");
         }
         for (int k = 0; k < 32; ++k) {
-            fprintf(stderr, "ts block %d:", 300 + k);
+            fprintf(stderr, "ts block %d:", RRT_TS_BASE + k);
             for (int e = 0; e < 16; ++e) fprintf(stderr, " %lld", d0.ts[k * 16 + e] ? (long long)(d0.ts[k * 16 + e] - d0.ts[0]) : -1ll);
             fprintf(stderr, "\n");
         }
