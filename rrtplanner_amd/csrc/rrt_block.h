@@ -298,7 +298,8 @@ struct BlockLds {
     alignas(16) GSlot gslot[NWAVE];
     alignas(16) GCtl gctl[BSM];
     alignas(8) uint16_t plist[(PIPE && BSM < 16) ? BSM : 1][PL_MAX];  // a group's list of in-flight lines of sight, filled by its waves
-    uint32_t oq_cnt[(PIPE && BSM < 16) ? BSM : 1], oq_ovf;  // worker groups: fill of a blocked sample's queue of open candidates, "a queue overflowed"
+    uint32_t oq_cnt[(PIPE && BSM < 16) ? BSM : 1], oq_ovf;
+    uint32_t qhist[16], qstage2;  // a big queue (BSM == 1): open candidates per sixteenth of the cost range; "nothing passed among the cheap ones"  // worker groups: fill of a blocked sample's queue of open candidates, "a queue overflowed"
 #ifdef RRT_STAMPS
     unsigned long long dbg[16];  // pipelined teams: phase cycles of wave 0 of the committer and of worker 1
 #endif
@@ -520,6 +521,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
         if (t == 0) L.help_any = 0;
         if (t < (int)(sizeof(L.oq_cnt) / sizeof(uint32_t))) L.oq_cnt[t] = 0;
         if (t == 0) L.oq_ovf = 0;
+        if (t < 16) L.qhist[t] = 0;
+        if (t == 0) L.qstage2 = 0;
     }
     __syncthreads();
 
@@ -1717,6 +1720,13 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                 }
                 __syncthreads();
                 const GCtl c = gctl[sl];
+                // which sixteenth of the cost range [lbc, bound) an open candidate's cost falls in (monotone in the cost)
+                auto qbin = [](double cn, double lo, double hi) -> int {
+                    const double w = hi - lo;
+                    if (!(w > 0.0)) return 0;
+                    const int b = (int)((cn - lo) * (16.0 / w));
+                    return b < 0 ? 0 : (b > 15 ? 15 : b);
+                };
                 bool by_queue = false;
                 if constexpr (GQ) {
                     // A sample whose two cheapest candidates are blocked (7 % of the samples: it sits behind a wall, dozens of cheaper
@@ -1765,6 +1775,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                                     } else if (open) {
                                         const unsigned long long cb = (unsigned long long)__double_as_longlong(cn);
                                         oq[qb + (uint32_t)__builtin_popcountll(om & ((1ull << lane) - 1ull))] = u32x4{e.x, e.y, (uint32_t)cb, (uint32_t)(cb >> 32)};
+                                        if constexpr (BSM == 1) __hip_atomic_fetch_add(&L.qhist[qbin(cn, c.lbc, c.bound)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                     }
                                 }
                             }
@@ -1781,7 +1792,81 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         if (uni32(L.oq_ovf) == 0u) {
                             by_queue = true;
                             const uint32_t nq = c.consume != 0u ? uni32(L.oq_cnt[sl]) : 0u;
-                            for (uint32_t e0 = 8u * (uint32_t)part; e0 < nq; e0 += 8u * (uint32_t)WPS) {
+                            // A BIG queue (hundreds of open candidates: a dense tree behind a wall) took three round trips of 128 tests, and
+                            // the walk of rrt.py:515-521 needs a dozen of them: the candidates in (cost, index) order up to the first one
+                            // that sees the sample.  So the cheap ones first: the histogram of the costs (filled while the queue was) names
+                            // the sixteenth b* of the cost range below which ~100 candidates lie; stage 1 tests those (entries dealt to the
+                            // waves one by one, so that every wave has a few); only if none of them passes the rest follows (stage 2).
+                            constexpr uint32_t QBIG = 128;
+                            const bool big = BSM == 1 && nq > QBIG;
+                            int bstar = 15;
+                            if (big) {
+                                uint32_t hc = lane < 16 ? L.qhist[lane] : 0u, inc = hc;
+                                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);
+                                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);
+                                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);
+                                inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);
+                                const u64 reach = __ballot(lane < 16 && inc >= 96u);
+                                bstar = reach ? (int)__builtin_ctzll(reach) : 15;
+                            }
+                            // one stage of tests over the entries this wave is dealt (entry w + 16 l in lane l): the selected ones, eight per
+                            // round trip
+                            auto test_dealt = [&](int blo, int bhi) {
+                                for (uint32_t q0 = 0; q0 < nq; q0 += 64u * (uint32_t)WPS) {
+                                    const uint32_t qe = q0 + (uint32_t)part + (uint32_t)WPS * (uint32_t)lane;
+                                    u32x4 e = {NONE, 0u, 0u, 0u};
+                                    bool sel = false;
+                                    if (qe < nq) {
+                                        e = oq[qe];
+                                        const int b = qbin(__longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z)), c.lbc, c.bound);
+                                        sel = b >= blo && b <= bhi;
+                                    }
+                                    u64 sm = __ballot(sel);
+                                    uint32_t res = 0;
+                                    while (sm) {
+                                        uint32_t a8[LOSB];
+                                        int l8[LOSB], nc = 0;
+#pragma unroll
+                                        for (int q8 = 0; q8 < LOSB; ++q8) {
+                                            a8[q8] = Xk;
+                                            l8[q8] = 0;
+                                            if (sm) {
+                                                l8[q8] = (int)__builtin_ctzll(sm);
+                                                sm &= sm - 1;
+                                                a8[q8] = (uint32_t)__builtin_amdgcn_readlane((int)e.y, l8[q8]);
+                                                nc = q8 + 1;
+                                            }
+                                        }
+                                        bool ok8[LOSB];
+                                        int cells8[LOSB];
+                                        los_batch(og, H, a8, nc, Xk, lane, ok8, cells8);
+#pragma unroll
+                                        for (int q8 = 0; q8 < LOSB; ++q8)
+                                            if (q8 < nc && lane == l8[q8]) res = (uint32_t)cells8[q8] | (ok8[q8] ? 0u : 0x80000000u);
+                                    }
+                                    if (sel) oq[qe].y = res;  // cells read; bit 31: blocked
+                                }
+                            };
+                            if (big) {
+                                test_dealt(0, bstar);
+                                __syncthreads();
+                                if (lead) {  // did one of the cheap candidates pass?  (stage 2 otherwise: everybody has to know)
+                                    bool pass = false;
+                                    for (uint32_t pq = (uint32_t)lane; pq < nq; pq += 64) {
+                                        const u32x4 e = oq[pq];
+                                        const int b = qbin(__longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z)), c.lbc, c.bound);
+                                        pass = pass || (b <= bstar && (e.y >> 31) == 0u);
+                                    }
+                                    const bool anyp = __ballot(pass) != 0;
+                                    if (lane == 0) L.qstage2 = anyp ? 0u : 1u;
+                                }
+                                __syncthreads();
+                                if (uni32(L.qstage2) != 0u) {
+                                    if (bstar < 15) test_dealt(bstar + 1, 15);
+                                    bstar = 15;
+                                }
+                            }
+                            for (uint32_t e0 = 8u * (uint32_t)part; !big && e0 < nq; e0 += 8u * (uint32_t)WPS) {
                                 const int nc = (int)(nq - e0 < 8u ? nq - e0 : 8u);
                                 uint32_t axy = Xk;
                                 if (lane < nc) axy = oq[e0 + (uint32_t)lane].y;  // (the entry's coordinates; the result of its test goes there)
@@ -1824,8 +1909,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                                     uint32_t ci = NONE;
                                     if (pq < nq) {
                                         const u32x4 e = oq[pq];
-                                        if ((e.y >> 31) == 0u) {
-                                            cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                                        const double ce = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+                                        // (a big queue: only the entries of the sixteenths up to b* were tested; the others still hold their
+                                        //  coordinates where the result goes, and none of them can come before a tested entry that passed)
+                                        if ((!big || qbin(ce, c.lbc, c.bound) <= bstar) && (e.y >> 31) == 0u) {
+                                            cn = ce;
                                             ci = e.x;
                                         }
                                     }
@@ -1839,7 +1927,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                                 for (uint32_t pq = (uint32_t)lane; pq < nq; pq += 64) {
                                     const u32x4 e = oq[pq];
                                     const double cn = __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
-                                    if (wi == NONE || !key_lt(wc, wi, cn, e.x)) {
+                                    if ((wi == NONE || !key_lt(wc, wi, cn, e.x)) && (!big || qbin(cn, c.lbc, c.bound) <= bstar)) {
                                         nt += 1;
                                         tcl += e.y & 0x7fffffffu;
                                     }
@@ -1852,6 +1940,8 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                                 if (lane < WPS) am = __uint_as_float(gslot[sl * WPS + lane].pad[0]);
                                 amin = grid_nn ? wave_min_f32_nonneg(am) : 0.0f;
                                 if (lane == 0) L.oq_cnt[sl] = 0;  // (the next block's waves append behind its own barriers)
+                                if (BSM == 1 && lane < 16) L.qhist[lane] = 0;
+                                if (BSM == 1 && lane == 0) L.qstage2 = 0;
                             }
                         }
                     }
@@ -1915,6 +2005,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                     L.oq_cnt[sl] = 0;
                     L.oq_ovf = 0;
                 }
+                if (GQ && BSM == 1 && lead && lane < 16) L.qhist[lane] = 0;
                 }  // !by_queue
             }
 #ifdef RRT_STAMPS
