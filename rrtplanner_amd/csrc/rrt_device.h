@@ -94,6 +94,39 @@ __device__ __forceinline__ bool key_lt(double c1, uint32_t i1, double c2, uint32
 // r2norm of an integer difference (rrt.py:24): sqrt of an exact integer < 2^53.
 __device__ __forceinline__ double sqrt_u32(uint32_t d2) { return sqrt((double)d2); }
 
+// A SHORT segment a -> b (fewer than 64 steps) for one cell per lane: the closed form of include/rrt_line.h with the segment's data in
+// scalar registers (a and b are wave-uniform), the cell as one byte offset into the grid, and the quotient without the fix-ups:
+//     m_k = floor((2 minor k + major) / (2 major));  the quotient's fractional part is a multiple of 1 / (2 major), so biased by
+//     half of that step it stays 1 / (4 major) >= 1/252 clear of the integers on both sides, and
+//         m_k = (int)(float(num) * rcp + 0.5 rcp)
+//     is exact for any rcp within a few ulp of 1 / (2 major) (num <= 8001; checked exhaustively for major <= 63, every minor and k,
+//     rcp off by +-3 ulp, fused or not: tools/check_short_line.py) -- seven vector instructions a cell instead of eighteen, which is
+//     what a worker group that tests hundreds of candidates of one sample is bound by.
+struct ShortLine {
+    int base, smaj, smin, major, minor;
+    float rcp, half;
+};
+__device__ __forceinline__ ShortLine short_line(uint32_t a, uint32_t b, int H) {
+    const int x0 = ux(a), y0 = uy(a), x1 = ux(b), y1 = uy(b);
+    const int dx = x1 - x0, dy = y1 - y0, adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    const int stx = x0 < x1 ? H : -H, sty = y0 < y1 ? 1 : -1;  // (the steps of rrt_line_setup, as byte strides of the row-major grid)
+    const bool xm = adx >= ady;
+    ShortLine l;
+    l.base = x0 * H + y0;
+    l.smaj = xm ? stx : sty;
+    l.smin = xm ? sty : stx;
+    l.major = xm ? adx : ady;
+    l.minor = xm ? ady : adx;
+    l.rcp = __builtin_amdgcn_rcpf((float)(l.major > 0 ? 2 * l.major : 1));
+    l.half = 0.5f * l.rcp;
+    return l;
+}
+__device__ __forceinline__ uint32_t short_line_cell(const ShortLine &l, int k) {
+    const int num = 2 * l.minor * k + l.major;
+    const int m = (int)__builtin_fmaf((float)num, l.rcp, l.half);
+    return (uint32_t)(l.base + l.smaj * k + l.smin * m);
+}
+
 // Line of sight a -> b (RRT.collisionfree, rrt.py:202-229) evaluated by one wavefront:
 // lane l tests cell k0+l of the closed-form walk (rrt_line.h); the ballot gives any-hit and
 // the first blocked cell.  `cells` = grid cells the reference's serial walk reads
@@ -125,11 +158,7 @@ __device__ __forceinline__ bool los_wave(const uint8_t *__restrict__ og, int H, 
     }
     if (L < 64) {
         bool occ = false;
-        if (lane <= L) {
-            int x, y;
-            rrt_line_cell(&l, lane, &x, &y);
-            occ = og[(uint32_t)(x * H + y)] != 0;
-        }
+        if (lane <= L) occ = og[short_line_cell(short_line(a, b, H), lane)] != 0;
         unsigned long long m = __ballot(occ);
         cells = m ? (int)__builtin_ctzll(m) + 1 : L + 1;
         return m == 0;
@@ -166,15 +195,11 @@ struct LosPending {
     uint8_t v;
 };
 __device__ __forceinline__ LosPending los_issue(const uint8_t *__restrict__ og, int H, uint32_t a, uint32_t b, int lane) {
-    const rrt_line_t l = rrt_line_setup(ux(a), uy(a), ux(b), uy(b));
+    const ShortLine l = short_line(a, b, H);  // (major and minor as in rrt_line_setup for any length; the cell only below 64 steps)
     LosPending p;
     p.major = l.major;
     p.v = 0;
-    if (l.major < 64 && lane <= l.major) {
-        int x, y;
-        rrt_line_cell(&l, lane, &x, &y);
-        p.v = og[(uint32_t)(x * H + y)];
-    }
+    if (l.major < 64 && lane <= l.major) p.v = og[short_line_cell(l, lane)];
     return p;
 }
 __device__ __forceinline__ bool los_finish(const LosPending &p, const uint8_t *__restrict__ og, int H, uint32_t a, uint32_t b, int lane,
@@ -189,22 +214,13 @@ __device__ __forceinline__ bool los_finish(const LosPending &p, const uint8_t *_
 // cell loads are in flight together, so a failed first test does not cost a second memory round trip.
 __device__ __forceinline__ void los_wave2(const uint8_t *__restrict__ og, int H, uint32_t a0, uint32_t a1, bool has1, uint32_t b, int lane,
                                           bool &ok0, int &cells0, bool &ok1, int &cells1) {
-    const rrt_line_t l0 = rrt_line_setup(ux(a0), uy(a0), ux(b), uy(b));
-    const rrt_line_t l1 = rrt_line_setup(ux(a1), uy(a1), ux(b), uy(b));
+    const ShortLine l0 = short_line(a0, b, H), l1 = short_line(a1, b, H);
     ok1 = false;
     cells1 = 0;
     if (l0.major < 64 && (!has1 || l1.major < 64)) {
         uint8_t v0 = 0, v1 = 0;
-        if (lane <= l0.major) {
-            int x, y;
-            rrt_line_cell(&l0, lane, &x, &y);
-            v0 = og[(uint32_t)(x * H + y)];
-        }
-        if (has1 && lane <= l1.major) {
-            int x, y;
-            rrt_line_cell(&l1, lane, &x, &y);
-            v1 = og[(uint32_t)(x * H + y)];
-        }
+        if (lane <= l0.major) v0 = og[short_line_cell(l0, lane)];
+        if (has1 && lane <= l1.major) v1 = og[short_line_cell(l1, lane)];
         const unsigned long long m0 = __ballot(v0 != 0), m1 = __ballot(v1 != 0);
         ok0 = m0 == 0;
         cells0 = m0 ? (int)__builtin_ctzll(m0) + 1 : l0.major + 1;
@@ -221,50 +237,28 @@ __device__ __forceinline__ void los_wave2(const uint8_t *__restrict__ og, int H,
 // Up to LOSB lines of sight a[c] -> b at once (c < nc, wave-uniform operands), every segment shorter than 64 cells
 // (one ballot each): all cell loads are in flight together.  cells[c] as in los_wave.
 constexpr int LOSB = 8;
-__device__ __forceinline__ void los_batch(const uint8_t *__restrict__ og, int H, const uint32_t (&a)[LOSB], int nc, uint32_t b, int lane,
-                                          bool (&ok)[LOSB], int (&cells)[LOSB]) {
-    rrt_line_t ln[LOSB];
-    uint8_t v[LOSB];
-#pragma unroll
-    for (int c = 0; c < LOSB; ++c) {
-        ln[c] = rrt_line_setup(ux(a[c]), uy(a[c]), ux(b), uy(b));
-        v[c] = 0;
-        if (c < nc && lane <= ln[c].major) {
-            int x, y;
-            rrt_line_cell(&ln[c], lane, &x, &y);
-            v[c] = og[(uint32_t)(x * H + y)];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < LOSB; ++c) {
-        const unsigned long long mb = __ballot(v[c] != 0);
-        ok[c] = mb == 0;
-        cells[c] = mb ? (int)__builtin_ctzll(mb) + 1 : ln[c].major + 1;
-    }
-}
-
-// The same for N lines of sight (N <= LOSB) with fewer registers held.
 template <int N>
 __device__ __forceinline__ void los_batch_n(const uint8_t *__restrict__ og, int H, const uint32_t (&a)[N], int nc, uint32_t b, int lane,
                                             bool (&ok)[N], int (&cells)[N]) {
-    rrt_line_t ln[N];
+    int major[N];
     uint8_t v[N];
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-        ln[c] = rrt_line_setup(ux(a[c]), uy(a[c]), ux(b), uy(b));
+        const ShortLine l = short_line(a[c], b, H);
+        major[c] = l.major;
         v[c] = 0;
-        if (c < nc && lane <= ln[c].major) {
-            int x, y;
-            rrt_line_cell(&ln[c], lane, &x, &y);
-            v[c] = og[(uint32_t)(x * H + y)];
-        }
+        if (c < nc && lane <= l.major) v[c] = og[short_line_cell(l, lane)];
     }
 #pragma unroll
     for (int c = 0; c < N; ++c) {
         const unsigned long long mb = __ballot(v[c] != 0);
         ok[c] = mb == 0;
-        cells[c] = mb ? (int)__builtin_ctzll(mb) + 1 : ln[c].major + 1;
+        cells[c] = mb ? (int)__builtin_ctzll(mb) + 1 : major[c] + 1;
     }
+}
+__device__ __forceinline__ void los_batch(const uint8_t *__restrict__ og, int H, const uint32_t (&a)[LOSB], int nc, uint32_t b, int lane,
+                                          bool (&ok)[LOSB], int (&cells)[LOSB]) {
+    los_batch_n<LOSB>(og, H, a, nc, b, lane, ok, cells);
 }
 
 }  // namespace rrtdev
