@@ -27,6 +27,10 @@ light)
     make -C rrtplanner_amd/csrc -j16 exp EXP="-DRRT_STAMPS -DRRT_STAMPS_LIGHT=0x8016" NAME=light > $O/light_build.log 2>&1; echo "light build rc=$?"
     (echo "## config 2 default (64+1), light stamps: committer [1] = block start .. part A done, [2] = .. rounds done, [4] = .. published, [15] = end-of-block barrier; worker [1] = resolve + hand over (+ take), [2] = go wait"
      RRT_STAMPS_DUMP=1 RRT_STAMPS_RAW=1 RRT_HIP_LIB=rrtplanner_amd/librrt_hip_exp_light.so timeout -k 10 200 python3 tools/stamps.py) > $O/dev_light.txt 2>&1; grep -E "kernel|raw" $O/dev_light.txt; grep "dbg2 groups\|dbg2 resolve>32" $O/dev_light.txt | tail -3 ;;
+pstamps)
+    # the barrier-free pipeline on config 4's share, one CU per query
+    make -C rrtplanner_amd/csrc -j16 stamps > $O/stamps_build.log 2>&1; echo "stamps build rc=$?"
+    (RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so timeout -k 10 200 python3 tools/pipe_stamps.py --n 20000 --queries 64 --team 1) > $O/dev_pstamps.txt 2>&1; cat $O/dev_pstamps.txt ;;
 stress)
     timeout -k 10 600 python3 tools/stress_team.py --reps 6 > $O/dev_stress.txt 2>&1; echo "stress rc=$?"; tail -n 15 $O/dev_stress.txt ;;
 esac

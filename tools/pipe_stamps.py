@@ -17,11 +17,12 @@ ap.add_argument("--alg", type=int, default=1)
 ap.add_argument("--queries", type=int, default=1)
 ap.add_argument("--grid", type=int, default=1024)
 ap.add_argument("--r", type=float, default=64.0)
+ap.add_argument("--team", type=int, default=1, help="cap on the CUs per query (0: as many as fit -- the team pipeline for a few CUs per query)")
 a = ap.parse_args()
 og = perlin_occupancygrid(a.grid, a.grid, seed=1)
 free = np.argwhere(og == 0)
 ctx = _ffi.Context(0); ctx.set_grid(hostprep.og_nonzero(og))
-b = _ffi.Batch(ctx, a.queries, a.n, team=1)
+b = _ffi.Batch(ctx, a.queries, a.n, team=(a.team or None))
 sg = np.random.default_rng(7); keep = []
 for q in range(a.queries):
     xs, xg = random_connected_pair(og, sg)
