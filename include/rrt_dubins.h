@@ -15,9 +15,11 @@
  *
  * Plain C, usable from HIP device code and from gcc.  The CPU oracle (oracle/dubins_oracle.c) and the HIP kernel include
  * this one header on purpose: the planner's decisions compare path lengths, so "bit-exact tree" needs bit-identical
- * arithmetic, and libm's and the device's sin / atan2 / acos are not that.  Everything here is built from + - * /, sqrt and
- * floor in a fixed order (both sides compile with -ffp-contract=off: no fused multiply-add, no reassociation), so gcc on
- * the host and hipcc on gfx950 produce the same bits.  What the oracle adds is its own sequential loop; the FORMULAS are
+ * arithmetic, and libm's and the device's sin / atan2 / acos are not that.  Everything here is built from + - * /, sqrt,
+ * floor and EXPLICIT fused multiply-adds (DUB_FMA: IEEE fma, one rounding -- v_fma_f64 on the device, fma() on the host) in a
+ * fixed order; both sides compile with -ffp-contract=off, so nothing else is fused and nothing is reassociated, and gcc on
+ * the host and hipcc on gfx950 produce the same bits.  (Round 4: until then every a * b + c was two instructions -- the
+ * polynomials, the reductions and the rotations of a word evaluation were 8 400 separate f64 multiplies and adds in the kernel.)  What the oracle adds is its own sequential loop; the FORMULAS are
  * checked separately against numpy / libm (tests/test_dubins.py: every reported word, integrated forward with numpy,
  * ends in the goal pose; lengths agree with an independent implementation to 1e-9).
  */
@@ -29,8 +31,25 @@
 
 #ifdef __HIPCC__
 #define RRT_DUB_FN __host__ __device__ static inline
+#define RRT_DUB_BIG_FN __host__ __device__ static __attribute__((noinline)) /* one copy in the kernel: a word evaluation is ~1 400 instructions */
 #else
 #define RRT_DUB_FN static inline
+#define RRT_DUB_BIG_FN static inline
+#endif
+
+#define DUB_FMA(a, b, c) __builtin_fma((a), (b), (c)) /* a * b + c with ONE rounding, on both sides */
+/* a * b + K for a CONSTANT K (the Horner steps).  The same fma; on the device written out as the three-operand instruction with
+ * K in scalar registers: left to itself the compiler picks the two-operand v_fmac_f64, whose addend is its destination, and copies
+ * every coefficient into vector registers first -- two moves per step, a quarter of a word evaluation's vector instructions. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double dub_fma_k(double a, double b, double k) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+#define DUB_FMA_K(a, b, k) dub_fma_k((a), (b), (k))
+#else
+#define DUB_FMA_K(a, b, k) __builtin_fma((a), (b), (k))
 #endif
 
 #define DUB_PI 3.141592653589793
@@ -51,7 +70,7 @@ typedef struct {
  * two selects behind it put right. */
 #define DUB_INV_TWOPI 0.15915494309189535
 RRT_DUB_FN double dub_mod2pi(double a) {
-    double r = a - DUB_TWOPI * floor(a * DUB_INV_TWOPI);
+    double r = DUB_FMA(-DUB_TWOPI, floor(a * DUB_INV_TWOPI), a);
     r = r < 0.0 ? r + DUB_TWOPI : r;
     return r >= DUB_TWOPI ? r - DUB_TWOPI : r;
 }
@@ -59,14 +78,27 @@ RRT_DUB_FN double dub_mod2pi(double a) {
 /* sin and cos of a (|a| up to a few hundred): quadrant by Cody-Waite reduction with a two-part pi/2, then the Taylor
  * polynomials on [-pi/4, pi/4] (truncation below 1e-17). */
 RRT_DUB_FN void dub_sincos(double a, double *s, double *c) {
-    const double k = floor(a * 0.6366197723675814 + 0.5); /* 2 / pi */
-    const double r = (a - k * 1.5707963267341256) - k * 6.077100506506192e-11; /* pi/2 = hi + lo, hi has 33 significant bits */
+    const double k = floor(DUB_FMA(a, 0.6366197723675814, 0.5)); /* 2 / pi */
+    const double r = DUB_FMA(-k, 6.077100506506192e-11, DUB_FMA(-k, 1.5707963267341256, a)); /* pi/2 = hi + lo, hi has 33 significant bits */
     const double z = r * r;
-    const double sp = r * (1.0 + z * (-1.0 / 6.0 + z * (1.0 / 120.0 + z * (-1.0 / 5040.0 + z * (1.0 / 362880.0 + z * (-1.0 / 39916800.0 +
-                      z * (1.0 / 6227020800.0 + z * (-1.0 / 1307674368000.0))))))));
-    const double cp = 1.0 + z * (-0.5 + z * (1.0 / 24.0 + z * (-1.0 / 720.0 + z * (1.0 / 40320.0 + z * (-1.0 / 3628800.0 + z * (1.0 / 479001600.0 +
-                      z * (-1.0 / 87178291200.0 + z * (1.0 / 20922789888000.0))))))));
-    const double kq = k - 4.0 * floor(k * 0.25); /* k mod 4 in {0, 1, 2, 3} */
+    double ps = -1.0 / 1307674368000.0, pc = 1.0 / 20922789888000.0; /* Horner, one fused step per coefficient */
+    ps = DUB_FMA_K(z, ps, 1.0 / 6227020800.0);
+    ps = DUB_FMA_K(z, ps, -1.0 / 39916800.0);
+    ps = DUB_FMA_K(z, ps, 1.0 / 362880.0);
+    ps = DUB_FMA_K(z, ps, -1.0 / 5040.0);
+    ps = DUB_FMA_K(z, ps, 1.0 / 120.0);
+    ps = DUB_FMA_K(z, ps, -1.0 / 6.0);
+    ps = DUB_FMA_K(z, ps, 1.0);
+    pc = DUB_FMA_K(z, pc, -1.0 / 87178291200.0);
+    pc = DUB_FMA_K(z, pc, 1.0 / 479001600.0);
+    pc = DUB_FMA_K(z, pc, -1.0 / 3628800.0);
+    pc = DUB_FMA_K(z, pc, 1.0 / 40320.0);
+    pc = DUB_FMA_K(z, pc, -1.0 / 720.0);
+    pc = DUB_FMA_K(z, pc, 1.0 / 24.0);
+    pc = DUB_FMA_K(z, pc, -0.5);
+    const double sp = r * ps;
+    const double cp = DUB_FMA_K(z, pc, 1.0);
+    const double kq = DUB_FMA(-4.0, floor(k * 0.25), k); /* k mod 4 in {0, 1, 2, 3} */
     if (kq == 0.0) {
         *s = sp;
         *c = cp;
@@ -101,17 +133,17 @@ RRT_DUB_FN double dub_atan_ratio(double num, double den) {
         t = 0.198912367379658; /* tan(pi / 16) */
         base = 0.19634954084936207;
     }
-    const double w = (num - t * den) / (den + t * num);
-    const double u = w * w;
+    const double w = DUB_FMA(-t, den, num) / DUB_FMA(t, num, den);
+    const double u = -(w * w);
     double acc = 1.0 / 15.0;
-    acc = 1.0 / 13.0 - u * acc;
-    acc = 1.0 / 11.0 - u * acc;
-    acc = 1.0 / 9.0 - u * acc;
-    acc = 1.0 / 7.0 - u * acc;
-    acc = 1.0 / 5.0 - u * acc;
-    acc = 1.0 / 3.0 - u * acc;
-    acc = 1.0 - u * acc;
-    return base + w * acc;
+    acc = DUB_FMA_K(u, acc, 1.0 / 13.0);
+    acc = DUB_FMA_K(u, acc, 1.0 / 11.0);
+    acc = DUB_FMA_K(u, acc, 1.0 / 9.0);
+    acc = DUB_FMA_K(u, acc, 1.0 / 7.0);
+    acc = DUB_FMA_K(u, acc, 1.0 / 5.0);
+    acc = DUB_FMA_K(u, acc, 1.0 / 3.0);
+    acc = DUB_FMA_K(u, acc, 1.0);
+    return DUB_FMA(w, acc, base);
 }
 
 /* atan2(y, x) in (-pi, pi]; atan2(0, 0) = 0 */
@@ -147,17 +179,18 @@ RRT_DUB_FN void dub_take(dub_path_t *best, int32_t word, double t, double p, dou
 /* (s0, c0), (s1, c1): sine and cosine of the two headings (dub_sincos(th0), dub_sincos(th1): a caller with discrete headings keeps
  * them in a table).  The sines and cosines of alpha = th0 - theta and beta = th1 - theta come from those by the rotation with
  * (cos theta, sin theta) = (dx, dy) / D, and cos(alpha - beta) from them: no series (round 2 ran three per word). */
-RRT_DUB_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, double s0, double c0, double x1, double y1, double th1, double s1, double c1,
+RRT_DUB_BIG_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, double s0, double c0, double x1, double y1, double th1, double s1, double c1,
                                       double rho) {
     const double dx = x1 - x0, dy = y1 - y0;
-    const double D = sqrt(dx * dx + dy * dy);
+    const double D = sqrt(DUB_FMA(dx, dx, dy * dy));
     const double d = D / rho;
     const double theta = dub_mod2pi(dub_atan2(dy, dx));
     const double alpha = dub_mod2pi(th0 - theta), beta = dub_mod2pi(th1 - theta);
     const double ct = D > 0.0 ? dx / D : 1.0, st = D > 0.0 ? dy / D : 0.0; /* (atan2(0, 0) = 0) */
-    const double sa = s0 * ct - c0 * st, ca = c0 * ct + s0 * st;
-    const double sb = s1 * ct - c1 * st, cb = c1 * ct + s1 * st;
-    const double cab = ca * cb + sa * sb;
+    const double sa = DUB_FMA(s0, ct, -(c0 * st)), ca = DUB_FMA(c0, ct, s0 * st);
+    const double sb = DUB_FMA(s1, ct, -(c1 * st)), cb = DUB_FMA(c1, ct, s1 * st);
+    const double cab = DUB_FMA(ca, cb, sa * sb);
+    const double d2 = 2.0 * d; /* (exact) */
     const double dsq = d * d;
     dub_path_t best;
     best.t = best.p = best.q = 0.0;
@@ -168,14 +201,14 @@ RRT_DUB_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, double s
      * cosines, LSL's itself: the very values the four separate calls returned */
     const double at_l = dub_atan2(cb - ca, d + sa - sb), at_r = dub_atan2(ca - cb, d - sa + sb);
     { /* LSL */
-        const double psq = 2.0 + dsq - 2.0 * cab + 2.0 * d * (sa - sb);
+        const double psq = DUB_FMA(d2, sa - sb, DUB_FMA(-2.0, cab, 2.0 + dsq));
         if (psq >= 0.0) {
             const double tmp = at_l;
             dub_take(&best, DUB_LSL, dub_mod2pi(tmp - alpha), sqrt(psq), dub_mod2pi(beta - tmp));
         }
     }
     { /* LSR */
-        const double psq = -2.0 + dsq + 2.0 * cab + 2.0 * d * (sa + sb);
+        const double psq = DUB_FMA(d2, sa + sb, DUB_FMA(2.0, cab, -2.0 + dsq));
         if (psq >= 0.0) {
             const double p = sqrt(psq);
             const double tmp = dub_atan2(-ca - cb, d + sa + sb) - dub_atan2(-2.0, p);
@@ -183,7 +216,7 @@ RRT_DUB_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, double s
         }
     }
     { /* RSL */
-        const double psq = -2.0 + dsq + 2.0 * cab - 2.0 * d * (sa + sb);
+        const double psq = DUB_FMA(-d2, sa + sb, DUB_FMA(2.0, cab, -2.0 + dsq));
         if (psq >= 0.0) {
             const double p = sqrt(psq);
             const double tmp = dub_atan2(ca + cb, d - sa - sb) - dub_atan2(2.0, p);
@@ -191,14 +224,14 @@ RRT_DUB_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, double s
         }
     }
     { /* RSR */
-        const double psq = 2.0 + dsq - 2.0 * cab + 2.0 * d * (sb - sa);
+        const double psq = DUB_FMA(d2, sb - sa, DUB_FMA(-2.0, cab, 2.0 + dsq));
         if (psq >= 0.0) {
             const double tmp = at_r;
             dub_take(&best, DUB_RSR, dub_mod2pi(alpha - tmp), sqrt(psq), dub_mod2pi(tmp - beta));
         }
     }
     { /* RLR */
-        const double tmp = (6.0 - dsq + 2.0 * cab + 2.0 * d * (sa - sb)) / 8.0;
+        const double tmp = DUB_FMA(d2, sa - sb, DUB_FMA(2.0, cab, 6.0 - dsq)) * 0.125;
         if (tmp <= 1.0 && tmp >= -1.0) {
             const double phi = at_r;
             const double p = dub_mod2pi(DUB_TWOPI - dub_acos(tmp));
@@ -207,7 +240,7 @@ RRT_DUB_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, double s
         }
     }
     { /* LRL */
-        const double tmp = (6.0 - dsq + 2.0 * cab + 2.0 * d * (sb - sa)) / 8.0;
+        const double tmp = DUB_FMA(d2, sb - sa, DUB_FMA(2.0, cab, 6.0 - dsq)) * 0.125;
         if (tmp <= 1.0 && tmp >= -1.0) {
             const double phi = (ca - cb == 0.0) ? at_l : -at_l; /* = dub_atan2(ca - cb, d + sa - sb) */
             const double p = dub_mod2pi(DUB_TWOPI - dub_acos(tmp));
@@ -238,8 +271,8 @@ RRT_DUB_FN void dub_advance(double x, double y, double th, int32_t kind, double 
     double s0, c0;
     dub_sincos(th, &s0, &c0);
     if (kind == 0) {
-        *ox = x + c0 * tau;
-        *oy = y + s0 * tau;
+        *ox = DUB_FMA(c0, tau, x);
+        *oy = DUB_FMA(s0, tau, y);
         *oth = th;
     } else if (kind > 0) {
         double s1, c1;
@@ -272,23 +305,23 @@ typedef struct {
  * the same bit for bit, and a wavefront whose samples lie on different segments evaluates one series, not one per branch. */
 RRT_DUB_FN void dub_advance_pre(double x, double y, double th, double s0, double c0, int32_t kind, double tau, double *ox, double *oy) {
     if (kind == 0) {
-        *ox = x + c0 * tau;
-        *oy = y + s0 * tau;
+        *ox = DUB_FMA(c0, tau, x);
+        *oy = DUB_FMA(s0, tau, y);
         return;
     }
     const double sg = kind > 0 ? 1.0 : -1.0;
     double s1, c1;
-    dub_sincos(th + sg * tau, &s1, &c1);
-    *ox = x + sg * (s1 - s0);
-    *oy = y - sg * (c1 - c0);
+    dub_sincos(DUB_FMA(sg, tau, th), &s1, &c1); /* (sg = +-1: the product is exact, the sum th +- tau as before) */
+    *ox = DUB_FMA(sg, s1 - s0, x);
+    *oy = DUB_FMA(-sg, c1 - c0, y);
 }
 
 /* dub_advance with sin / cos of th given and sin / cos of the new heading returned */
 RRT_DUB_FN void dub_advance_sc(double x, double y, double th, double s0, double c0, int32_t kind, double tau, double *ox, double *oy, double *oth,
                                double *os, double *oc) {
     if (kind == 0) {
-        *ox = x + c0 * tau;
-        *oy = y + s0 * tau;
+        *ox = DUB_FMA(c0, tau, x);
+        *oy = DUB_FMA(s0, tau, y);
         *oth = th;
         *os = s0;
         *oc = c0;
@@ -366,8 +399,8 @@ RRT_DUB_FN void dub_sweep_cell(const dub_sweep_t *s, int32_t k, int32_t *cx, int
         dt = tau - s->t;
     }
     dub_advance_pre(bx, by, bth, bs, bc, kind, dt, &x, &y);
-    *cx = (int32_t)floor(s->x0 + x * s->rho + 0.5);
-    *cy = (int32_t)floor(s->y0 + y * s->rho + 0.5);
+    *cx = (int32_t)floor(DUB_FMA(x, s->rho, s->x0) + 0.5);
+    *cy = (int32_t)floor(DUB_FMA(y, s->rho, s->y0) + 0.5);
 }
 
 #endif /* RRT_DUBINS_H */

@@ -74,6 +74,7 @@ struct DbLds {
     uint32_t fail;                        // a wave waited DB_STALL_TICKS without any sample retiring: everybody leaves (never seen; the exit every wave reaches)
     unsigned long long stat[6];
     alignas(16) double htab[3][256];  // angle, sine, cosine of the discrete headings (DubCfg::htab)
+    uint32_t slots[NWAVE][64];        // the streams' cell starts of a step
     unsigned long long dbg[8];  // diagnostic build: [0] samples resolved again, [1] retirements that priced younger vertices, [2] those vertices
 };
 
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     }
     DubCfg dc{D->rho, D->nh, bv.W, bv.H};
     dc.htab = (const RRT_LDS double *)&L.htab[0][0];
+    dc.inv_rho = 1.0 / D->rho;
     const uint32_t *samples = bv.samples + (size_t)q * bv.n_cap;
     uint32_t *nodes_g = bv.nodes + (size_t)q * bv.node_stride;
     double *vcost = bv.vcost + (size_t)q * bv.node_stride;
@@ -121,9 +123,11 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     // radius of the first record stream: the rewire radius, but at least two cells (Dubins-RRT has no near set, and a tiny
     // radius would leave the nearest-vertex search to the doubling below)
     int rad0 = 0;
+    uint32_t rr0 = 0;  // its square: the stream deals every vertex nearer than that
     {
         const uint32_t two = (uint32_t)((2 << cshift) * (2 << cshift));
         const uint32_t rr = (star && r2 > two) ? r2 : two;
+        rr0 = rr;
         rad0 = (rr >= (1u << 23)) ? 4096 : (int)sqrtf((float)(rr - 1));
         while (rad0 > 0 && (uint32_t)(rad0 * rad0) > rr - 1) --rad0;
         while ((uint32_t)((rad0 + 1) * (rad0 + 1)) <= rr - 1) ++rad0;
@@ -163,10 +167,13 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
     auto cell_of = [&](uint32_t X) -> int { return (ux(X) >> cshift) * ncy + (uy(X) >> cshift); };
 
     // The records of the cells that the box of half-width `rad` around X touches, as ONE packed stream: lane l of a step takes
-    // record 64 * step + l of the concatenation of the cells' arrays (exclusive prefix sum of the fill counts over the lanes, the
-    // cell of a record by bisection over that prefix with ds_bpermute), 64 cells at a time.  f(record, live) once per step.
+    // record 64 * step + l of the concatenation of the cells' arrays (exclusive prefix sum of the fill counts over the lanes),
+    // 64 cells at a time.  f(record, live) once per step.  The stream of rrt_pipe.h (round 4; until then this kernel found a
+    // record's cell by a bisection of eight dependent ds_bpermute per step and dealt the box's corners too):
+    // `keep_d2`: every vertex at a squared distance up to this must be dealt; cells farther away than that are left out.
     // Records of vertices at or above `jsnap` (inserted after the caller's snapshot) are dealt as dead lanes.
-    auto stream_box = [&](uint32_t X, int rad, uint32_t jsnap, auto &&f) {
+    volatile RRT_LDS uint32_t *slots = (volatile RRT_LDS uint32_t *)L.slots[wave];  // (lanes talk to each other through it: every access as written)
+    auto stream_box = [&](uint32_t X, int rad, uint32_t keep_d2, uint32_t jsnap, auto &&f) {
         // a tree of up to 64 vertices: all of them in one step, from the vertex arrays instead of the cells' (the same answers; a
         // start pose that nothing can be connected to, and the first samples of every run, would otherwise walk ever larger boxes)
         const bool tiny = jsnap <= DB_TINY;
@@ -179,8 +186,12 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             if (tiny) {
                 tcnt = lane == 0 ? jsnap : 0u;  // (one "cell": the vertex arrays)
             } else if (cbase + lane < ncr) {
-                const int ci = cbase + lane, cell = (cx0 + ci / ny) * ncy + (cy0 + ci % ny);
-                tcnt = cellcnt[cell];
+                const int ci = cbase + lane, ccx = cx0 + ci / ny, ccy = cy0 + ci % ny, cell = ccx * ncy + ccy;
+                // squared distance of the sample to the cell's rectangle
+                const int xl = ccx << cshift, xh = xl + (1 << cshift) - 1, yl = ccy << cshift, yh = yl + (1 << cshift) - 1;
+                const int ddx = x < xl ? xl - x : (x > xh ? x - xh : 0), ddy = y < yl ? yl - y : (y > yh ? y - yh : 0);
+                const uint32_t md2 = (uint32_t)(ddx * ddx + ddy * ddy);
+                tcnt = md2 <= keep_d2 ? cellcnt[cell] : 0u;
                 toff = (uint32_t)cell * (uint32_t)ccap;
             }
             uint32_t incl = tcnt;
@@ -191,18 +202,30 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
             incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const uint32_t pre = incl - tcnt;  // lanes past the last cell hold `total`: never <= a live record number
+            const uint32_t pre = incl - tcnt;
+            // Which cell a record belongs to, without a search: every non-empty cell whose first record falls into this step writes
+            // its number into that record's slot (64 words of LDS per wave), the lanes read their slots and a running maximum over
+            // the lanes (DPP) carries the number to the records behind it; the lanes in front of the step's first cell start belong
+            // to the cell the last step ended in.
+            int cur_c = 0;
             auto fetch = [&](uint32_t base) -> u32x4 {
                 const uint32_t idx = base + (uint32_t)lane;
-                uint32_t lo = 0;  // the largest cell c with pre[c] <= idx
-#pragma unroll
-                for (uint32_t bit = 32; bit != 0; bit >>= 1) {
-                    const uint32_t cand = lo + bit;
-                    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cand << 2), (int)pre);
-                    lo = v <= idx ? cand : lo;
-                }
-                const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)pre);
-                const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lo << 2), (int)toff);
+                slots[lane] = NONE;
+                const uint32_t rel = pre - base;
+                __builtin_amdgcn_wave_barrier();
+                if (tcnt != 0u && rel < 64u) slots[rel] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                int cv = (int)slots[lane];  // (NONE = -1)
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x111, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x112, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x114, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x118, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x142, 0xa, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x143, 0xc, 0xf, false));
+                cv = cv < 0 ? cur_c : cv;
+                cur_c = __builtin_amdgcn_readlane(cv, 63);
+                const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute(cv << 2, (int)pre);
+                const uint32_t coff = (uint32_t)__builtin_amdgcn_ds_bpermute(cv << 2, (int)toff);
                 if (tiny) {
                     const uint32_t k = idx < total ? idx : 0u;
                     const unsigned long long cbits = (unsigned long long)__double_as_longlong(vcost[k]);
@@ -470,7 +493,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
             uint32_t ld2 = NONE, lidx = NONE, lxy = 0, lvl = 0, lvh = 0;  // this lane's nearest record
             float m1f = FINF, m2f = FINF;                                 // smallest / second smallest bound among this lane's hits
             uint32_t m1idx = NONE, m1xy = 0, m1vl = 0, m1vh = 0;
-            stream_box(xq, rad0, jsnap, [&](const u32x4 rc, bool live) {
+            stream_box(xq, rad0, rr0 - 1u, jsnap, [&](const u32x4 rc, bool live) {
                 const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                 const bool nearer = d2 < ld2 || (d2 == ld2 && live && rc.y < lidx);
                 ld2 = nearer ? d2 : ld2;
@@ -499,7 +522,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                 radn = 2 * radn + 1;
                 ld2 = NONE;
                 lidx = NONE;
-                stream_box(xq, radn, jsnap, [&](const u32x4 rc, bool live) {
+                stream_box(xq, radn, (uint32_t)radn * (uint32_t)radn, jsnap, [&](const u32x4 rc, bool live) {
                     const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                     const bool nearer = d2 < ld2 || (d2 == ld2 && live && rc.y < lidx);
                     ld2 = nearer ? d2 : ld2;
@@ -598,7 +621,7 @@ __global__ __launch_bounds__(TPB) void rrt_dubins_block_kernel(BatchView bv) {
                         if (tail) buf[lane] = mv;
                         nbuf = nbuf > 64u ? nbuf - 64u : 0u;
                     };
-                    stream_box(xq, rad0, jsnap, [&](const u32x4 rc, bool live) {
+                    stream_box(xq, rad0, rr0 - 1u, jsnap, [&](const u32x4 rc, bool live) {
                         const uint32_t d2 = live ? dist2(rc.x, xq) : NONE;
                         const double V = __longlong_as_double((long long)(((unsigned long long)rc.w << 32) | rc.z));
                         const bool take = d2 < r2 && rc.y != nn_idx && rc.y != skip && (double)db_lower_bound(V, d2) < cb;

@@ -31,6 +31,14 @@ pstamps)
     # the barrier-free pipeline on config 4's share, one CU per query
     make -C rrtplanner_amd/csrc -j16 stamps > $O/stamps_build.log 2>&1; echo "stamps build rc=$?"
     (RRT_HIP_LIB=rrtplanner_amd/librrt_hip_stamps.so timeout -k 10 200 python3 tools/pipe_stamps.py --n 20000 --queries 64 --team 1) > $O/dev_pstamps.txt 2>&1; cat $O/dev_pstamps.txt ;;
+c5)
+    timeout -k 10 400 python3 bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline > $O/dev_c5.json 2> $O/dev_c5.err; echo "c5 rc=$?"
+    python3 -c "
+import json; d=json.load(open('$O/dev_c5.json')); print('c5 ms_per_step %.1f kernel_ms %.1f value %.4g' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))" ;;
+dubtests)
+    timeout -k 10 800 python -m pytest tests/test_dubins.py -m gpu -x -q > $O/dev_dubtests.log 2>&1; rc=$?
+    echo "dubins tests rc=$rc"; tail -n 5 $O/dev_dubtests.log
+    [ $rc -eq 0 ] || exit $rc ;;
 stress)
     timeout -k 10 600 python3 tools/stress_team.py --reps 6 > $O/dev_stress.txt 2>&1; echo "stress rc=$?"; tail -n 15 $O/dev_stress.txt ;;
 esac
