@@ -211,7 +211,10 @@ RRT_DUB_BIG_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, doub
         const double psq = DUB_FMA(d2, sa + sb, DUB_FMA(2.0, cab, -2.0 + dsq));
         if (psq >= 0.0) {
             const double p = sqrt(psq);
-            const double tmp = dub_atan2(-ca - cb, d + sa + sb) - dub_atan2(-2.0, p);
+            /* atan2(A, B) - atan2(-2, p) as ONE arctangent: the angle of (B, A) turned back by that of (p, -2), i.e. of
+             * (B p - 2 A, A p + 2 B); the two differ by a multiple of 2 pi at most, which the reductions below take out */
+            const double A = -ca - cb, B = d + sa + sb;
+            const double tmp = dub_atan2(DUB_FMA(A, p, 2.0 * B), DUB_FMA(B, p, -(2.0 * A)));
             dub_take(&best, DUB_LSR, dub_mod2pi(tmp - alpha), p, dub_mod2pi(tmp - dub_mod2pi(beta)));
         }
     }
@@ -219,7 +222,9 @@ RRT_DUB_BIG_FN dub_path_t dub_shortest_sc(double x0, double y0, double th0, doub
         const double psq = DUB_FMA(-d2, sa + sb, DUB_FMA(2.0, cab, -2.0 + dsq));
         if (psq >= 0.0) {
             const double p = sqrt(psq);
-            const double tmp = dub_atan2(ca + cb, d - sa - sb) - dub_atan2(2.0, p);
+            /* atan2(A, B) - atan2(2, p): the angle of (B p + 2 A, A p - 2 B) */
+            const double A = ca + cb, B = d - sa - sb;
+            const double tmp = dub_atan2(DUB_FMA(A, p, -(2.0 * B)), DUB_FMA(B, p, 2.0 * A));
             dub_take(&best, DUB_RSL, dub_mod2pi(alpha - tmp), p, dub_mod2pi(beta - tmp));
         }
     }

@@ -1462,8 +1462,11 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
             LosPending lp;
             lp.major = 0;
             lp.v = 0;
+            // the sample's word of the `sampled` bitmap: an agent-scope load that is a memory round trip where the grid's cells are L2
+            // hits -- asked for here, in front of the near-set stream, not between the stream and the lines of sight (loads return
+            // in order: there the tests' answers waited for it)
+            if (lead && act) bm_word = ld_u32<COH>(&at32(bitmap, cell >> 5));
             if (lead && act && !grid_nn) {  // started here, finished behind the near-set stream
-                bm_word = ld_u32<COH>(&at32(bitmap, cell >> 5));
                 vsxy = node_xy(vs);
                 lp = los_issue(og, H, vsxy, Xk, lane);
             }
@@ -1608,7 +1611,6 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
                         vsxy = node_xy(vs);
                     }
                     cnear_s = Vs + sqrt_u24(d2s);
-                    bm_word = ld_u32<COH>(&at32(bitmap, cell >> 5));
                     if (star) {
                         // the cheapest entry at or above the bound, where the two cheapest of the ball tell (see finish_parent)
                         amin = (tt.i1 == NONE) ? FINF : !(tt.c1 < cnear_s) ? lower_f32(tt.c1) : (tt.i2 == NONE) ? FINF : !(tt.c2 < cnear_s) ? lower_f32(tt.c2) : 0.0f;
