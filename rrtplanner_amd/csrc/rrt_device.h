@@ -52,6 +52,10 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// `old` operand of a DPP step whose result goes into a signed max: the identity of that max (a lane without a source keeps it), which is
+// what lets the compiler fold the step into ONE v_max_i32_dpp -- with -1 ("no cell") it was a move of the constant, a DPP move and the max.
+constexpr int DPP_SMAX_ID = (int)0x80000000;
+
 // Wave-wide unsigned sum, result uniform in every lane (same DPP ladder, additive).
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);

@@ -227,12 +227,12 @@ __global__ __launch_bounds__(TPB) void rrt_pipe_kernel(BatchView bv) {
                 if (tcnt != 0u && rel < 64u) slots[rel] = (uint32_t)lane;
                 __builtin_amdgcn_wave_barrier();
                 int cv = (int)slots[lane];  // (NONE = -1)
-                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x111, 0xf, 0xf, false));
-                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x112, 0xf, 0xf, false));
-                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x114, 0xf, 0xf, false));
-                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x118, 0xf, 0xf, false));
-                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x142, 0xa, 0xf, false));
-                cv = max(cv, __builtin_amdgcn_update_dpp(-1, cv, 0x143, 0xc, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(DPP_SMAX_ID, cv, 0x111, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(DPP_SMAX_ID, cv, 0x112, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(DPP_SMAX_ID, cv, 0x114, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(DPP_SMAX_ID, cv, 0x118, 0xf, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(DPP_SMAX_ID, cv, 0x142, 0xa, 0xf, false));
+                cv = max(cv, __builtin_amdgcn_update_dpp(DPP_SMAX_ID, cv, 0x143, 0xc, 0xf, false));
                 cv = cv < 0 ? cur_c : cv;
                 cur_c = __builtin_amdgcn_readlane(cv, 63);
                 const uint32_t cpre = (uint32_t)__builtin_amdgcn_ds_bpermute(cv << 2, (int)pre);
