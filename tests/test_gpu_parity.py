@@ -59,6 +59,30 @@ def test_collisionfree_all_pairs_12x12(gpu_ctx):
         assert ok == free[k] and c == cells[k]
 
 
+def test_collisionfree_every_short_segment(gpu_ctx):
+    """Every segment of fewer than 64 steps (the device evaluates their cells without the integer fix-up of the closed form:
+    rrt_device.h short_line_cell), from two start cells to every cell within 63 of them, on a sparse random grid: decision and cell
+    count against the oracle's serial walk (rrt.py:202-229)."""
+    rng = np.random.default_rng(11)
+    g = (rng.uniform(size=(160, 150)) < 0.01).astype(np.uint8)
+    gpu_ctx.set_grid(g)
+    for (cx, cy) in ((80, 75), (66, 70)):
+        g[cx, cy] = 0
+    gpu_ctx.set_grid(g)
+    segs = []
+    for (cx, cy) in ((80, 75), (66, 70)):
+        for dx in range(-63, 64):
+            for dy in range(-63, 64):
+                segs.append((cx, cy, cx + dx, cy + dy))
+                if (dx + dy) % 7 == 0:
+                    segs.append((cx + dx, cy + dy, cx, cy))
+    seg = np.array(segs, dtype=np.int32)
+    free, cells = gpu_ctx.prim_collisionfree(seg)
+    for k in range(len(seg)):
+        ok, c = oracle.collisionfree(g, seg[k, :2], seg[k, 2:])
+        assert ok == free[k] and c == cells[k], seg[k]
+
+
 def test_collisionfree_noise_and_long_segments(gpu_ctx):
     g = GA.grid("noise200")
     gpu_ctx.set_grid(g)
