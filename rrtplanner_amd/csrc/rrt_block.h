@@ -56,6 +56,12 @@ constexpr int TEAM_MAX = 64;
 #ifndef RRT_PIPE_LAG
 #define RRT_PIPE_LAG 2  // blocks a pipelined team's workers run ahead of the commit (a batch without Informed queries)
 #endif
+#ifndef RRT_PIPE_LAG_SMALL
+#define RRT_PIPE_LAG_SMALL 1  // ... where one wave resolves a sample (teams of up to 4 workers).  Such a team's period is its workers'
+                              // throughput, not the ring's latency: a second block in flight buys nothing and costs the commit its masks
+                              // and re-resolutions (measured, profiles/r04_experiments.md §9: config 4's share 6.45 -> 6.16 ms, teams of 8 and more
+                              // workers 4 - 10 % slower with one block)
+#endif
 #ifndef RRT_PIPE_LAG_INF
 #define RRT_PIPE_LAG_INF 2  // ... when the batch may hold Informed queries (a commit that moves the ellipse voids the blocks in flight)
 #endif
@@ -267,9 +273,9 @@ struct ParRound {  // pipelined committer: the samples re-resolved side by side,
 
 // How far the workers run ahead of the commit: two blocks (every record carries masks against the samples of BOTH blocks in
 // flight; a commit of an Informed query that ends early or moves the ellipse voids both).
-template <bool PIPE, bool INF>
+template <bool PIPE, bool INF, int BSM>
 struct PipeShape {
-    static constexpr int LAG = PIPE ? (INF ? RRT_PIPE_LAG_INF : RRT_PIPE_LAG) : 0;
+    static constexpr int LAG = PIPE ? (INF ? RRT_PIPE_LAG_INF : (BSM >= 16 ? RRT_PIPE_LAG_SMALL : RRT_PIPE_LAG)) : 0;
     static_assert(LAG <= NPMAX, "a record carries masks for NPMAX blocks in flight");
     static constexpr int NP = LAG > 0 ? LAG : 1;      // previous blocks a record / the commit looks at (array extents)
     static constexpr int NSLOT = PIPE ? LAG + 1 : 1;  // record and state buffers in the hand-off area: by block number modulo NSLOT
@@ -278,7 +284,7 @@ struct PipeShape {
 // The static LDS of the block kernel (one object per workgroup, whatever its role).
 template <int G, int BSM, bool PIPE, bool INF>
 struct BlockLds {
-    static constexpr int SB = BSM * G, NP = PipeShape<PIPE, INF>::NP;
+    static constexpr int SB = BSM * G, NP = PipeShape<PIPE, INF, BSM>::NP;
     alignas(16) u32x2 nnx[(BSM <= BS ? BSM : 1) * NWAVE];     // per own sample, per wave: {d2, idx} (phase A; not with more than 16 samples per member)
     alignas(16) BRec brec[PIPE ? 2 : 1][SB];  // (a pipelined committer: this block's records and the next one's)
     uint32_t xq_next[PIPE ? 2 : 1][PIPE ? 64 : 1];  // pipelined committer: the next block's samples and whether its records are in,
@@ -331,7 +337,7 @@ __device__ __forceinline__ void rrt_block_body(BatchView bv, BlockLds<G, BSM, PI
     constexpr bool WIDE = BSM > BS;
     static_assert(!PIPE || G > 1, "a pipeline needs a team");
     static_assert(PIPE == (ROLE != ROLE_ALL), "roles are the halves of a pipelined team");
-    constexpr int LAG = PipeShape<PIPE, INF>::LAG, NP = PipeShape<PIPE, INF>::NP, NSLOT = PipeShape<PIPE, INF>::NSLOT;
+    constexpr int LAG = PipeShape<PIPE, INF, BSM>::LAG, NP = PipeShape<PIPE, INF, BSM>::NP, NSLOT = PipeShape<PIPE, INF, BSM>::NSLOT;
     constexpr int SB = BSM * G;  // samples per (super-)block: one lane of the committing wave each; BSM per member
     // steps (of 64 records) of the near-set stream a wave has in flight: two where one wave streams a sample's whole ball, one
     // where a group of waves shares it (a wave of a group rarely has a second step, and the team kernels sit at the register cap:
