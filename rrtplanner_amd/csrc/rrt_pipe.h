@@ -30,7 +30,8 @@
 #include "rrt_block.h"
 
 #ifndef RRT_PIPE_STREAM_DEPTH
-#define RRT_PIPE_STREAM_DEPTH 3  // steps of a record stream in flight (measured 1..4: profiles/r03_experiments.md)
+#define RRT_PIPE_STREAM_DEPTH 4  // steps of a record stream in flight (round 3 measured 1..4 and took 3; with round 4's cheaper steps 4 is
+                                 // 5 % faster at 256 queries, 5 and 6 are not: profiles/r04_experiments.md §10)
 #endif
 
 namespace rrtdev {
@@ -38,7 +39,7 @@ namespace rrtdev {
 constexpr int PP_BUF = 128;  // collected entries per wave (pass 2): a step appends at most 64, a flush follows as soon as 64 are in
 constexpr uint32_t PP_TINY = 64;  // a tree of up to this many vertices is looked at as a whole, one vertex per lane (no cell streams)
 #ifndef RRT_PIPE_KB
-#define RRT_PIPE_KB 16
+#define RRT_PIPE_KB 32  // (16 until round 4: 1 - 3 % slower on config 4's shapes)
 #endif
 constexpr int PP_KB = RRT_PIPE_KB;  // most heads retired in one pass (<= 32)
 constexpr int PP_WIN = 64;   // samples in flight ahead of retirement
