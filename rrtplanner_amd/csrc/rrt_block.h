@@ -74,7 +74,10 @@ constexpr int NPMAX = RRT_NPMAX;
 // 16-bit entries, so that the committer settles "an inserted sample in flight is a cheaper parent" (nine in ten of the samples a
 // commit has to look at again) lane-parallel, without a line-of-sight test of its own.  Entry: bits 0-5 sample, 6-7 set (0 = oldest
 // previous block ... NP = this block), 8-14 cells the test read, 15 free; order: oldest block first, sample order = node order.
-constexpr int PL_MAX = 12, PL_WORDS = 3;
+#ifndef RRT_PL_MAX
+#define RRT_PL_MAX 12
+#endif
+constexpr int PL_MAX = RRT_PL_MAX, PL_WORDS = (RRT_PL_MAX + 3) / 4;
 constexpr int BREC_WORDS = 10 + 3 * NPMAX + PL_WORDS;  // 8-byte words of an owner's record (BRec below): 152 bytes for two blocks in flight
 // per query: [go | fail | state (NPMAX + 1 slots of 64 bytes) | records (NPMAX + 1 slots of 64) | arrival flags (65 x 128) | go2goal answers (65 x 16)]
 constexpr int TEAM_OFF_GO = 128, TEAM_OFF_FAIL = 256, TEAM_OFF_STATE = 384, TEAM_OFF_REC = 1024;
