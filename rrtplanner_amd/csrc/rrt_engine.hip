@@ -494,6 +494,9 @@ struct TeamShape {
     bool pipe = false;
     int cus() const { return team > 1 ? qpad * (team + (pipe ? 1 : 0)) : 0; }  // workgroups that must be resident together
 };
+static TeamShape pick_team(int Q, int want, bool allow_pipe, int cus);
+// The batch got two CUs per query without a committer, by itself (no cap from the caller, pipelines allowed): see rrt_batch_launch.
+static bool two_cus_run_the_pipeline(const rrt_batch *b);
 static TeamShape pick_team(int Q, int want, bool allow_pipe, int cus) {
     TeamShape t;
     t.qpad = (Q + 7) & ~7;
@@ -716,7 +719,7 @@ extern "C" int rrt_batch_set_query(rrt_batch *b, int32_t q, const rrt_query *qu)
         for (int k = 0; k < qu->n; ++k) b->stage8[(size_t)k] = (uint8_t)qu->headings[k];
         HIPCHK(ctx, hipMemcpyAsync(b->d_shead + (size_t)q * b->n_cap, b->stage8.data(), (size_t)qu->n, hipMemcpyHostToDevice, ctx->stream));
     }
-    const bool pipe1 = b->use_block && b->team == 1 && !(b->flags & RRT_FLAG_NOPIPE1) && qu->alg != RRT_ALG_INFORMED;
+    const bool pipe1 = b->use_block && (b->team == 1 || two_cus_run_the_pipeline(b)) && !(b->flags & RRT_FLAG_NOPIPE1) && qu->alg != RRT_ALG_INFORMED;
     cell_geometry(W, H, (int64_t)d.r2_rewire, b->n_cap, pipe1 ? RRT_CELL_DIV_PIPE : RRT_CELL_DIV, d.cell_shift, d.ncx, d.ncy, d.cell_cap);
     arm_desc(d);
     HIPCHK(ctx, hipMemcpyAsync(b->d_samples + (size_t)q * b->n_cap, b->stage.data(), (size_t)qu->n * sizeof(uint32_t),
@@ -862,6 +865,10 @@ static size_t expand_lds_bytes(int lds_chunks) {
     return (size_t)lds_chunks * CHUNK * sizeof(uint32_t);  // dynamic part: the node cache (lists and slots are static LDS)
 }
 
+static bool two_cus_run_the_pipeline(const rrt_batch *b) {
+    return b->use_block && b->team == 2 && !b->pipe_team && b->team_want >= TEAM_MAX && !(b->flags & (RRT_FLAG_NOPIPE | RRT_FLAG_NOPIPE1));
+}
+
 extern "C" int rrt_batch_launch(rrt_batch *b) {
     if (!b) return fail(nullptr, RRT_E_ARG, "rrt_batch_launch: NULL");
     rrt_ctx *ctx = b->ctx;
@@ -877,6 +884,15 @@ extern "C" int rrt_batch_launch(rrt_batch *b) {
         int team = b->one_cu_once ? 1 : b->team;
         bool pipe_shape = b->pipe_team;
         const bool continuation = b->one_cu_once;  // (of a launch that stopped at a block boundary: the block kernel takes it from there)
+        if (two_cus_run_the_pipeline(b) && !continuation) {
+            // 86 - 128 queries: two CUs per query fit, a third (the committer of a pipelined team) does not.  The unpipelined team of
+            // two is slower than the barrier-free pipeline on ONE of them (config 4's query x 128: 12.7 ms against 11.0; config 2's:
+            // 45.6 against 37.4, profiles/r04_experiments.md §11) -- unless the batch holds Informed queries, which that kernel does not run.
+            bool any_inf = false;
+            for (const QDesc &d : b->h_desc)
+                if (d.status == ST_RUNNING && d.alg == 2) any_inf = true;
+            if (!any_inf) team = 1;
+        }
         b->one_cu_once = false;
         cu_release(ctx->device, b->claimed_cus);  // (a launch that was never synchronised)
         b->claimed_cus = 0;

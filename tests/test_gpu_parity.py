@@ -368,6 +368,50 @@ def test_batch_of_queries_matches_single_queries(gpu_ctx):
     b.close()
 
 
+@pytest.mark.parametrize("with_informed", [False, True])
+def test_two_cus_per_query_without_a_committer_runs_the_pipeline(gpu_ctx, with_informed):
+    """100 queries: two CUs per query fit, a third (a pipelined team's committer) does not.  Without Informed queries the batch runs the
+    one-CU pipeline (faster than the unpipelined team of two); with one, the team of two; a caller's cap of 2 keeps the team.  Results
+    equal the oracle's either way."""
+    og = perlin_occupancygrid(300, 260, seed=6)
+    og8 = oracle.og_u8(og)
+    gpu_ctx.set_grid(og8)
+    free = np.argwhere(og8 == 0)
+    sg = np.random.default_rng(12)
+    Q, n = 100, 500
+    r2 = hostprep.radius_threshold(24)
+    for cap in (None, 2):
+        b = _ffi.Batch(gpu_ctx, Q, n, team=cap)
+        keep, refs, algs = [], [], []
+        for q in range(Q):
+            xs, xg = random_connected_pair(og, sg)
+            samples = hostprep.draw_free_samples(np.random.default_rng(2000 + q), free, n)
+            alg = 2 if (with_informed and q == 7) else q % 2
+            kw = dict(goal_d2=hostprep.goal_threshold(5), Cmat=hostprep.rotation_to_world_frame(xs, xg)) if alg == 2 else {}
+            qu, k = _ffi.make_query(alg, n, xs, xg, samples, r2_rewire=r2, **kw)
+            keep.append(k)
+            b.set_query(q, qu)
+            algs.append(alg)
+            refs.append(None if alg == 2 else oracle.plan(og8, n, alg, xs, xg, samples, r2_rewire=r2))
+        b.launch()
+        b.sync()
+        if cap is None and not with_informed:
+            assert b.kernel_name() == "rrt_pipe_kernel"
+        else:
+            assert b.kernel_name().startswith("rrt_expand_block_kernel<2, 16, false")
+        for q in range(Q):
+            if algs[q] == 2:
+                continue  # (needs the host's unit-ball stream to go on: not this test's subject)
+            res = b.get_result(q)
+            st, ro = refs[q]
+            live = ro.j + (1 if ro.found else 0)
+            assert res.status == st and res.j == ro.j and res.vgoal == ro.vgoal, q
+            assert np.array_equal(res.pts[:live], ro.pts[:live]), q
+            assert np.array_equal(res.parent[:live], ro.parent[:live]), q
+            assert np.array_equal(res.vcost[:live], ro.vcost[:live]), q
+        b.close()
+
+
 @pytest.mark.parametrize("pipe1", [True, False])
 def test_more_queries_than_compute_units_one_cu_each(gpu_ctx, pipe1):
     """300 queries on one CU each (more workgroups than the device has CUs: the last ones start when the first have finished), the
